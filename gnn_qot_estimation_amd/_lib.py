@@ -1,0 +1,117 @@
+"""ctypes binding of ``libqot_gnn.so`` (the C ABI declared in ``include/qot_gnn.h``).
+
+There is no CPU fallback: if the shared library is missing or a call returns non-zero the
+caller gets an exception.  Tensors cross the boundary as raw device pointers plus sizes;
+the current torch stream is passed so launches are ordered with torch's own work (and are
+captured by ``torch.cuda.CUDAGraph``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqot_gnn.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_f = C.c_float
+_u64 = C.c_uint64
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
+SIGNATURES = {
+    "qot_abi_version": (_int, []),
+    "qot_error_string": (C.c_char_p, [_int]),
+    "qot_csr_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "qot_csr_build": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "qot_i64_to_i32": (_int, [_p, _p, _i64, _p]),
+    "qot_batch_ptr": (_int, [_p, _i64, _i64, _p, _p]),
+    "qot_embed_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
+    "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
+                                 _i64, _int, _int, _p]),
+    "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
+    "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
+    "qot_nnconv_bwd_edge": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
+                                   _int, _p]),
+    "qot_act_fwd": (_int, [_p, _p, _i64, _f, _f, _u64, _p, _p]),
+    "qot_act_bwd": (_int, [_p, _p, _p, _i64, _f, _f, _u64, _p, _p]),
+    "qot_pool_fwd": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "qot_pool_bwd": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p]),
+    "qot_gat_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p]),
+    "qot_gat_bwd_dst": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p]),
+    "qot_gat_bwd_src": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p]),
+    "qot_bn_partials_floats": (_sz, [_i64, _int]),
+    "qot_bn_stats": (_int, [_p, _i64, _int, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "qot_bn_apply": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
+    "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p]),
+    "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p]),
+    "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),
+}
+
+_lib = None
+
+
+class QotError(RuntimeError):
+    """A libqot_gnn entry point returned a non-zero status."""
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile ``csrc/*.hip`` for gfx950 into ``libqot_gnn.so`` (in-tree)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libqot_gnn.so failed:\n" + res.stdout[-4000:] + res.stderr[-8000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QotError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gnn_qot_estimation_amd/csrc` -- there is no CPU fallback for the HIP path"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.qot_abi_version() != 1:
+        raise QotError("libqot_gnn ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().qot_error_string(code).decode()
+        raise QotError(f"{what} failed with status {code}: {msg}")
+
+
+def call(name: str, *args):
+    """Invoke ``name`` with the current stream appended; raise on a non-zero status."""
+    lib = load()
+    check(getattr(lib, name)(*args, stream()), name)

@@ -1,0 +1,114 @@
+"""Build-owned ``Data`` / ``Batch`` containers with the layout of SURVEY.md Appendix C.
+
+The models only duck-type ``data`` (``.x .edge_index .edge_attr .batch .node_ids``, plus
+``.y .num_graphs .to()`` used by the harness at ``topological_training/train.py:108-117``),
+so a PyG ``Batch`` works unchanged; these classes exist because PyG is not a dependency.
+``Batch.from_data_list`` restates the collate rules the reference relies on
+(``topological_training/train.py:93-95`` via PyG ``DataLoader``): node tensors concatenated
+on dim 0, ``edge_index`` on dim 1 with the running node offset, ``batch``/``ptr`` built,
+attributes whose name contains ``index`` offset and all others (``node_ids``!) not.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+
+class Data:
+    """One graph (or, as ``Batch``, many).  Plain attribute bag."""
+
+    _TENSOR_FIELDS = ("x", "edge_index", "edge_attr", "y", "node_ids", "batch", "ptr")
+
+    def __init__(self, x=None, edge_index=None, edge_attr=None, y=None, node_ids=None, num_nodes=None):
+        self.x = x
+        self.edge_index = edge_index
+        self.edge_attr = edge_attr
+        self.y = y
+        self.node_ids = node_ids
+        self.batch = None
+        self.ptr = None
+        self._num_nodes = num_nodes
+
+    @property
+    def num_nodes(self) -> int:
+        if self._num_nodes is not None:
+            return self._num_nodes
+        if self.x is not None:
+            return self.x.shape[0]
+        if self.node_ids is not None:
+            return self.node_ids.shape[0]
+        if self.batch is not None:
+            return self.batch.shape[0]
+        return int(self.edge_index.max()) + 1 if self.edge_index.numel() else 0
+
+    @property
+    def num_edges(self) -> int:
+        return 0 if self.edge_index is None else self.edge_index.shape[1]
+
+    def to(self, device, non_blocking: bool = False):
+        out = self.__class__.__new__(self.__class__)
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if not k.startswith("_qot")})
+        for f in self._TENSOR_FIELDS:
+            v = getattr(self, f, None)
+            if isinstance(v, torch.Tensor):
+                setattr(out, f, v.to(device, non_blocking=non_blocking))
+        return out
+
+
+class Batch(Data):
+    """Block-diagonal batch of independent graphs (no edge crosses graphs)."""
+
+    num_graphs: int = 0
+
+    @classmethod
+    def from_data_list(cls, graphs: Iterable[Data]) -> "Batch":
+        graphs = list(graphs)
+        out = cls()
+        sizes = [g.num_nodes for g in graphs]
+        offsets = [0]
+        for s in sizes:
+            offsets.append(offsets[-1] + s)
+        out.num_graphs = len(graphs)
+        out._num_nodes = offsets[-1]
+        out.ptr = torch.tensor(offsets, dtype=torch.long)
+        out.batch = torch.repeat_interleave(torch.arange(len(graphs)), torch.tensor(sizes, dtype=torch.long)) \
+            if graphs else torch.zeros(0, dtype=torch.long)
+
+        def cat(name, dim=0):
+            vals = [getattr(g, name) for g in graphs]
+            if not vals or any(v is None for v in vals):
+                return None
+            return torch.cat(vals, dim=dim)
+
+        out.x = cat("x")
+        out.edge_attr = cat("edge_attr")
+        out.node_ids = cat("node_ids")  # NOT offset (name has no 'index')
+        out.y = cat("y")
+        eis = [g.edge_index + off for g, off in zip(graphs, offsets[:-1])]
+        out.edge_index = torch.cat(eis, dim=1) if eis else torch.zeros(2, 0, dtype=torch.long)
+        return out
+
+
+def shard_graphs(batch: Batch, rank: int, world: int) -> Batch:
+    """Contiguous graph range of ``batch`` for ``rank`` (data-parallel split)."""
+    b = batch.num_graphs
+    lo = (b * rank) // world
+    hi = (b * (rank + 1)) // world
+    ptr = batch.ptr
+    n0, n1 = int(ptr[lo]), int(ptr[hi])
+    out = Batch()
+    out.num_graphs = hi - lo
+    out._num_nodes = n1 - n0
+    out.ptr = ptr[lo:hi + 1] - n0
+    out.batch = batch.batch[n0:n1] - lo
+    out.x = None if batch.x is None else batch.x[n0:n1]
+    out.node_ids = None if batch.node_ids is None else batch.node_ids[n0:n1]
+    ei = batch.edge_index
+    keep = (ei[1] >= n0) & (ei[1] < n1)
+    out.edge_index = ei[:, keep] - n0
+    out.edge_attr = None if batch.edge_attr is None else batch.edge_attr[keep]
+    if batch.y is not None:
+        per = batch.y.shape[0] // max(b, 1)
+        out.y = batch.y[lo * per:hi * per]
+    return out

@@ -1,0 +1,89 @@
+// Shared device helpers for libqot_gnn (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qot_gnn.h"
+
+#define QOT_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t _e = hipGetLastError();         \
+        if (_e != hipSuccess) return (int)_e;      \
+    } while (0)
+
+#define QOT_HIP(call)                              \
+    do {                                           \
+        hipError_t _e = (call);                    \
+        if (_e != hipSuccess) return (int)_e;      \
+    } while (0)
+
+namespace qot {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+    return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float4 scale4(float s, float4 a) {
+    return make_float4(s * a.x, s * a.y, s * a.z, s * a.w);
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// Sum over an aligned group of G consecutive lanes (G power of two <= 64).  Only lanes of
+// the same group exchange data, so a wave may hold groups with different trip counts as
+// long as each group is uniformly active.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__host__ __device__ constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// counter-based dropout RNG: one 32-bit draw per element
+__device__ __forceinline__ uint32_t rng32(uint64_t seed, uint64_t step, uint64_t idx) {
+    uint64_t z = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (idx + 0xD1B54A32D192ED03ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+inline int grid_for(int64_t work, int per_block) { return (int)((work + per_block - 1) / per_block); }
+
+}  // namespace qot
+
+#define QOT_DISPATCH_H(H, ...)                  \
+    switch (H) {                                \
+        case 16:  { constexpr int kH = 16;  __VA_ARGS__; } break;  \
+        case 32:  { constexpr int kH = 32;  __VA_ARGS__; } break;  \
+        case 64:  { constexpr int kH = 64;  __VA_ARGS__; } break;  \
+        case 128: { constexpr int kH = 128; __VA_ARGS__; } break;  \
+        case 256: { constexpr int kH = 256; __VA_ARGS__; } break;  \
+        default: return QOT_ERR_UNSUPPORTED;    \
+    }
+
+#define QOT_DISPATCH_D(D, ...)                  \
+    switch (D) {                                \
+        case 1: { constexpr int kD = 1; __VA_ARGS__; } break;  \
+        case 2: { constexpr int kD = 2; __VA_ARGS__; } break;  \
+        case 3: { constexpr int kD = 3; __VA_ARGS__; } break;  \
+        case 4: { constexpr int kD = 4; __VA_ARGS__; } break;  \
+        case 5: { constexpr int kD = 5; __VA_ARGS__; } break;  \
+        case 6: { constexpr int kD = 6; __VA_ARGS__; } break;  \
+        case 7: { constexpr int kD = 7; __VA_ARGS__; } break;  \
+        case 8: { constexpr int kD = 8; __VA_ARGS__; } break;  \
+        default: return QOT_ERR_UNSUPPORTED;    \
+    }

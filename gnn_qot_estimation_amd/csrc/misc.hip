@@ -1,0 +1,448 @@
+// Embedding lookup, leaky_relu+dropout, global mean pool, BatchNorm(+ReLU), LUT row
+// gather/scatter.  Reference sites: topological_training/models.py:12,51-52 (Embedding),
+// :54-55,58-59 (leaky_relu + Dropout), :61 ([PyG-ext] global_mean_pool);
+// lightpath_training/models.py:14,31-32 ([PyG-ext] BatchNorm + relu), :39-40 (x[lut_mask]).
+// All HBM-bound: 16-B accesses per lane, rows contiguous across a lane group.
+#include "common.hpp"
+
+namespace qot {
+
+// ----------------------------------------------------------------------------- rows
+__global__ void rows_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                   float* __restrict__ out, int64_t n, int C4) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * C4) return;
+    int64_t r = t / C4;
+    int c = (int)(t - r * C4) * 4;
+    st4(out + r * C4 * 4 + c, ld4(src + (int64_t)idx[r] * C4 * 4 + c));
+}
+
+__global__ void rows_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                    float* __restrict__ out, int64_t n, int C4) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * C4) return;
+    int64_t r = t / C4;
+    int c = (int)(t - r * C4) * 4;
+    st4(out + (int64_t)idx[r] * C4 * 4 + c, ld4(src + r * C4 * 4 + c));
+}
+
+// Embedding backward.  ids repeat in every graph (node_ids is NOT offset by collate), so
+// thousands of rows hit the same V table rows: pre-reduce a block's rows in an LDS copy of
+// the table, then one float atomic per touched table element per block.
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g,
+                                                        const int32_t* __restrict__ ids,
+                                                        float* __restrict__ gt, int64_t N, int V, int H,
+                                                        int rows_per_block) {
+    extern __shared__ float tab[];
+    const int VH = V * H;
+    if (LDS_TABLE) {
+        for (int t = threadIdx.x; t < VH; t += blockDim.x) tab[t] = 0.f;
+        __syncthreads();
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+    const int64_t total = (r1 - r0) * H;
+    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+        int64_t r = r0 + t / H;
+        int c = (int)(t % H);
+        float val = g[r * H + c];
+        if (LDS_TABLE) atomicAdd(&tab[ids[r] * H + c], val);
+        else atomicAdd(&gt[(int64_t)ids[r] * H + c], val);
+    }
+    if (LDS_TABLE) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < VH; t += blockDim.x) {
+            float val = tab[t];
+            if (val != 0.f) atomicAdd(&gt[t], val);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- activation
+__device__ __forceinline__ uint64_t hash64(uint64_t seed, uint64_t step, uint64_t idx4) {
+    uint64_t z = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (idx4 * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <bool BWD>
+__global__ void act_kernel(const float* __restrict__ a, const float* __restrict__ yref,
+                           float* __restrict__ o, int64_t n4, float slope, uint32_t thr16,
+                           float keep_scale, uint64_t seed, const int64_t* __restrict__ step_counter) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    float4 in = ld4(a + 4 * t);
+    float vi[4] = {in.x, in.y, in.z, in.w};
+    float vr[4];
+    if (BWD) { float4 r = ld4(yref + 4 * t); vr[0] = r.x; vr[1] = r.y; vr[2] = r.z; vr[3] = r.w; }
+    uint64_t z = 0;
+    if (thr16) z = hash64(seed, (uint64_t)step_counter[0], (uint64_t)t);
+    float vo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bool keep = thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= thr16) : true;
+        float ks = keep ? keep_scale : 0.f;
+        if (BWD) vo[c] = vi[c] * ks * (vr[c] > 0.f ? 1.0f : slope);
+        else     vo[c] = (vi[c] > 0.f ? vi[c] : slope * vi[c]) * ks;
+    }
+    st4(o + 4 * t, make_float4(vo[0], vo[1], vo[2], vo[3]));
+}
+
+// ----------------------------------------------------------------------------- pool
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x,
+                                                       const int32_t* __restrict__ ptr,
+                                                       float* __restrict__ out, int H) {
+    __shared__ float4 red[256];
+    const int TPR = H / 4;
+    const int RPB = 256 / TPR;
+    const int sub = threadIdx.x % TPR;
+    const int slot = threadIdx.x / TPR;
+    const int64_t b = blockIdx.x;
+    const int beg = ptr[b], end = ptr[b + 1];
+    float4 acc = f4zero();
+    if (slot < RPB)
+        for (int64_t r = beg + slot; r < end; r += RPB) acc = add4(acc, ld4(x + r * H + 4 * sub));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < TPR) {
+        float4 s = red[threadIdx.x];
+        for (int k = 1; k < RPB; ++k) s = add4(s, red[k * TPR + threadIdx.x]);
+        int cnt = end - beg;
+        st4(out + b * H + 4 * threadIdx.x, scale4(1.0f / (float)(cnt > 1 ? cnt : 1), s));
+    }
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ ptr,
+                                const int32_t* __restrict__ batch, float* __restrict__ gx, int64_t N,
+                                int H4) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= N * H4) return;
+    int64_t r = t / H4;
+    int c = (int)(t - r * H4) * 4;
+    int b = batch[r];
+    int cnt = ptr[b + 1] - ptr[b];
+    st4(gx + r * H4 * 4 + c, scale4(1.0f / (float)(cnt > 1 ? cnt : 1), ld4(go + (int64_t)b * H4 * 4 + c)));
+}
+
+// ----------------------------------------------------------------------------- batch norm
+// Column statistics in two stages: each block reduces a contiguous row chunk into
+// partials[blk, 2, C]; a one-block finalize combines the partials in fp64.  Sums are taken
+// on x - x[0,:] (shifted-data form) so E[x^2]-E[x]^2 cancellation stays benign in fp32.
+constexpr int kBnMaxBlocks = 2048;
+inline int bn_blocks(int64_t N) {
+    int64_t b = (N + 63) / 64;
+    if (b < 1) b = 1;
+    return (int)(b > kBnMaxBlocks ? kBnMaxBlocks : b);
+}
+
+// MODE 0: s1 = sum(x - shift), s2 = sum((x-shift)^2)
+// MODE 1: s1 = sum(dy'), s2 = sum(dy' * xhat)   (dy' = dy * [y > 0] when relu)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partials,
+    int64_t N, int C, int relu) {
+    __shared__ float4 r1[256];
+    __shared__ float4 r2[256];
+    const int C4 = C / 4;
+    const int RPB = 256 / C4;
+    const int sub = threadIdx.x % C4;
+    const int slot = threadIdx.x / C4;
+    const int nblk = gridDim.x;
+    const int64_t chunk = (N + nblk - 1) / nblk;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk;
+    const int64_t r1e = (r0 + chunk < N) ? r0 + chunk : N;
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (slot < RPB) {
+        const int c = 4 * sub;
+        float4 sh, mu, rs;
+        if (MODE == 0) sh = ld4(x + c);
+        else { mu = ld4(mean + c); rs = ld4(rstd + c); }
+        for (int64_t r = r0 + slot; r < r1e; r += RPB) {
+            float4 xv = ld4(x + r * C + c);
+            if (MODE == 0) {
+                float4 d = sub4(xv, sh);
+                s1 = add4(s1, d);
+                s2 = make_float4(fmaf(d.x, d.x, s2.x), fmaf(d.y, d.y, s2.y), fmaf(d.z, d.z, s2.z), fmaf(d.w, d.w, s2.w));
+            } else {
+                float4 g = ld4(dy + r * C + c);
+                if (relu) {
+                    float4 yv = ld4(y + r * C + c);
+                    g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
+                }
+                float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z, (xv.w - mu.w) * rs.w);
+                s1 = add4(s1, g);
+                s2 = make_float4(fmaf(g.x, xh.x, s2.x), fmaf(g.y, xh.y, s2.y), fmaf(g.z, xh.z, s2.z), fmaf(g.w, xh.w, s2.w));
+            }
+        }
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 a = r1[threadIdx.x], b = r2[threadIdx.x];
+        for (int k = 1; k < RPB; ++k) { a = add4(a, r1[k * C4 + threadIdx.x]); b = add4(b, r2[k * C4 + threadIdx.x]); }
+        st4(partials + ((int64_t)blockIdx.x * 2) * C + 4 * threadIdx.x, a);
+        st4(partials + ((int64_t)blockIdx.x * 2 + 1) * C + 4 * threadIdx.x, b);
+    }
+}
+
+__global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const float* __restrict__ partials,
+                                         int nblk, int64_t N, int C, float eps, float momentum,
+                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                         float* __restrict__ rmean, float* __restrict__ rvar) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partials[((int64_t)b * 2) * C + c];
+        s2 += (double)partials[((int64_t)b * 2 + 1) * C + c];
+    }
+    double dn = (double)N;
+    double m1 = s1 / dn;
+    double var = s2 / dn - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    double mu = (double)x[c] + m1;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        double unb = (N > 1) ? var * dn / (dn - 1.0) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nblk, int C,
+                                       float* __restrict__ gw, float* __restrict__ gb) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partials[((int64_t)b * 2) * C + c];
+        s2 += (double)partials[((int64_t)b * 2 + 1) * C + c];
+    }
+    gb[c] = (float)s1;
+    gw[c] = (float)s2;
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ y, int64_t N, int C4,
+                                int relu) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= N * C4) return;
+    int c = (int)(t % C4) * 4;
+    float4 xv = ld4(x + 4 * t), mu = ld4(mean + c), rs = ld4(rstd + c), wv = ld4(w + c), bv = ld4(b + c);
+    float4 o = make_float4(fmaf((xv.x - mu.x) * rs.x, wv.x, bv.x), fmaf((xv.y - mu.y) * rs.y, wv.y, bv.y),
+                           fmaf((xv.z - mu.z) * rs.z, wv.z, bv.z), fmaf((xv.w - mu.w) * rs.w, wv.w, bv.w));
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    st4(y + 4 * t, o);
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ w,
+                                    const float* __restrict__ gw, const float* __restrict__ gb,
+                                    float* __restrict__ gx, int64_t N, int C4, int relu, int batch_stats) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= N * C4) return;
+    int c = (int)(t % C4) * 4;
+    float4 g = ld4(dy + 4 * t);
+    if (relu) {
+        float4 yv = ld4(y + 4 * t);
+        g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
+    }
+    float4 rs = ld4(rstd + c), wv = ld4(w + c);
+    float4 o;
+    if (batch_stats) {
+        float4 xv = ld4(x + 4 * t), mu = ld4(mean + c), a = ld4(gw + c), b = ld4(gb + c);
+        const float in = 1.0f / (float)N;
+        o.x = wv.x * rs.x * (g.x - b.x * in - (xv.x - mu.x) * rs.x * a.x * in);
+        o.y = wv.y * rs.y * (g.y - b.y * in - (xv.y - mu.y) * rs.y * a.y * in);
+        o.z = wv.z * rs.z * (g.z - b.z * in - (xv.z - mu.z) * rs.z * a.z * in);
+        o.w = wv.w * rs.w * (g.w - b.w * in - (xv.w - mu.w) * rs.w * a.w * in);
+    } else {
+        o = make_float4(g.x * wv.x * rs.x, g.y * wv.y * rs.y, g.z * wv.z * rs.z, g.w * wv.w * rs.w);
+    }
+    st4(gx + 4 * t, o);
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+static const char* kErrNames[] = {"ok", "unsupported width / edge_dim (no CPU fallback)", "bad argument"};
+
+extern "C" int qot_abi_version(void) { return QOT_ABI_VERSION; }
+
+extern "C" const char* qot_error_string(int code) {
+    if (code == 0) return kErrNames[0];
+    if (code == QOT_ERR_UNSUPPORTED) return kErrNames[1];
+    if (code == QOT_ERR_BADARG) return kErrNames[2];
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown qot error";
+}
+
+extern "C" int qot_embed_fwd(const float* table, const int32_t* ids, float* out, int64_t N, int V, int H,
+                             qot_stream_t stream) {
+    if (N < 0 || (H & 3) || H <= 0) return (H & 3) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!table || !ids || !out) return QOT_ERR_BADARG;
+    rows_gather_kernel<<<grid_for(N * (H / 4), 256), 256, 0, (hipStream_t)stream>>>(table, ids, out, N, H / 4);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, int64_t N,
+                             int V, int H, qot_stream_t stream) {
+    if (N < 0 || V <= 0 || H <= 0) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!grad_out || !ids || !grad_table) return QOT_ERR_BADARG;
+    const size_t lds = (size_t)V * H * 4;
+    if (lds <= 64 * 1024) {
+        int rpb = 2048;
+        embed_bwd_kernel<true><<<grid_for(N, rpb), 256, lds, (hipStream_t)stream>>>(grad_out, ids, grad_table, N, V, H, rpb);
+    } else {
+        int rpb = 256;
+        embed_bwd_kernel<false><<<grid_for(N, rpb), 256, 0, (hipStream_t)stream>>>(grad_out, ids, grad_table, N, V, H, rpb);
+    }
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+static int act_launch(bool bwd, const float* a, const float* yref, float* o, int64_t n, float slope, float p,
+                      uint64_t seed, const int64_t* step_counter, hipStream_t stream) {
+    if (n < 0 || (n & 3)) return (n & 3) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
+    if (n == 0) return QOT_OK;
+    if (!a || !o || (bwd && !yref) || p < 0.f || p >= 1.f) return QOT_ERR_BADARG;
+    uint32_t thr = 0;
+    float ks = 1.0f;
+    if (p > 0.f && step_counter) {
+        thr = (uint32_t)(p * 65536.0f + 0.5f);
+        if (thr > 65535u) thr = 65535u;
+        ks = 1.0f / (1.0f - p);
+    }
+    int64_t n4 = n / 4;
+    if (bwd) act_kernel<true><<<grid_for(n4, 256), 256, 0, stream>>>(a, yref, o, n4, slope, thr, ks, seed, step_counter);
+    else     act_kernel<false><<<grid_for(n4, 256), 256, 0, stream>>>(a, yref, o, n4, slope, thr, ks, seed, step_counter);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_act_fwd(const float* x, float* y, int64_t n, float slope, float p, uint64_t seed,
+                           const int64_t* step_counter, qot_stream_t stream) {
+    return act_launch(false, x, nullptr, y, n, slope, p, seed, step_counter, (hipStream_t)stream);
+}
+
+extern "C" int qot_act_bwd(const float* grad_y, const float* y_or_x, float* grad_x, int64_t n, float slope,
+                           float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream) {
+    return act_launch(true, grad_y, y_or_x, grad_x, n, slope, p, seed, step_counter, (hipStream_t)stream);
+}
+
+extern "C" int qot_pool_fwd(const float* x, const int32_t* ptr, float* out, int64_t B, int H,
+                            qot_stream_t stream) {
+    if (B < 0) return QOT_ERR_BADARG;
+    if ((H & 3) || H <= 0 || H > 1024) return QOT_ERR_UNSUPPORTED;
+    if (B == 0) return QOT_OK;
+    if (!ptr || !out) return QOT_ERR_BADARG;
+    pool_fwd_kernel<<<(int)B, 256, 0, (hipStream_t)stream>>>(x, ptr, out, H);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_pool_bwd(const float* grad_out, const int32_t* ptr, const int32_t* batch, float* grad_x,
+                            int64_t N, int64_t B, int H, qot_stream_t stream) {
+    if (N < 0 || B < 0) return QOT_ERR_BADARG;
+    if ((H & 3) || H <= 0) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!grad_out || !ptr || !batch || !grad_x) return QOT_ERR_BADARG;
+    pool_bwd_kernel<<<grid_for(N * (H / 4), 256), 256, 0, (hipStream_t)stream>>>(grad_out, ptr, batch, grad_x, N, H / 4);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" size_t qot_bn_partials_floats(int64_t N, int C) {
+    if (N < 0 || C <= 0) return 0;
+    return (size_t)bn_blocks(N) * 2 * (size_t)C;
+}
+
+extern "C" int qot_bn_stats(const float* x, int64_t N, int C, float eps, float momentum, float* mean,
+                            float* rstd, float* running_mean, float* running_var, float* partials,
+                            qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
+    if (!x || !mean || !rstd || !partials || ((running_mean == nullptr) != (running_var == nullptr)))
+        return QOT_ERR_BADARG;
+    int nblk = bn_blocks(N);
+    bn_partial_kernel<0><<<nblk, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, nullptr, partials, N, C, 0);
+    QOT_LAUNCH_CHECK();
+    bn_finalize_stats_kernel<<<grid_for(C, 256), 256, 0, stream>>>(x, partials, nblk, N, C, eps, momentum, mean, rstd, running_mean, running_var);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
+                            const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream) {
+    if (N < 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!x || !mean || !rstd || !w || !b || !y) return QOT_ERR_BADARG;
+    bn_apply_kernel<<<grid_for(N * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(x, mean, rstd, w, b, y, N, C / 4, relu);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_bn_bwd_reduce(const float* grad_y, const float* y, const float* x, const float* mean,
+                                 const float* rstd, float* gw, float* gb, int64_t N, int C, int relu,
+                                 float* partials, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
+    if (!grad_y || !x || !mean || !rstd || !gw || !gb || !partials || (relu && !y)) return QOT_ERR_BADARG;
+    int nblk = bn_blocks(N);
+    bn_partial_kernel<1><<<nblk, 256, 0, stream>>>(x, grad_y, y, mean, rstd, partials, N, C, relu);
+    QOT_LAUNCH_CHECK();
+    bn_finalize_bwd_kernel<<<grid_for(C, 256), 256, 0, stream>>>(partials, nblk, C, gw, gb);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const float* mean,
+                                const float* rstd, const float* w, const float* gw, const float* gb,
+                                float* grad_x, int64_t N, int C, int relu, int batch_stats,
+                                qot_stream_t stream) {
+    if (N < 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!grad_y || !rstd || !w || !grad_x || (relu && !y)) return QOT_ERR_BADARG;
+    if (batch_stats && (!x || !mean || !gw || !gb)) return QOT_ERR_BADARG;
+    bn_bwd_apply_kernel<<<grid_for(N * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        grad_y, y, x, mean, rstd, w, gw, gb, grad_x, N, C / 4, relu, batch_stats);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,
+                               qot_stream_t stream) {
+    if (n_idx < 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (n_idx == 0) return QOT_OK;
+    if (!x || !idx || !out) return QOT_ERR_BADARG;
+    rows_gather_kernel<<<grid_for(n_idx * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(x, idx, out, n_idx, C / 4);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_rows_scatter(const float* grad_out, const int32_t* idx, float* grad_x, int64_t n_idx,
+                                int C, qot_stream_t stream) {
+    if (n_idx < 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (n_idx == 0) return QOT_OK;
+    if (!grad_out || !idx || !grad_x) return QOT_ERR_BADARG;
+    rows_scatter_kernel<<<grid_for(n_idx * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(grad_out, idx, grad_x, n_idx, C / 4);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

@@ -1,0 +1,272 @@
+// TransformerConv (heads = 1, edge features, root weight) -- fused edge-softmax-aggregate.
+// Replaces [PyG-ext] TransformerConv.propagate reached from
+// topological_training/models.py:53: 3 gathers [E,H], lin_edge
+// materialisation [E,H], a 3-pass scatter softmax and a scatter_add become ONE pass over
+// the destination-sorted CSR.
+//
+// Mapping: a group of TPR = H/4 consecutive lanes owns one destination node; every lane
+// holds 4 channels (one 16-B load per row per lane -> a row read is one contiguous
+// H*4-byte burst).  64/TPR destinations per wave.  The edge embedding is never formed:
+//   <q_i, k_j + We ea> = <q_i, k_j> + <We^T q_i, ea>        (D-vector per destination)
+//   sum_e a_e (v_j + We ea_e) = sum_e a_e v_j + We (sum_e a_e ea_e)
+// so per edge only the 4 raw edge features are read.  Online softmax (running max / sum).
+#include "common.hpp"
+
+namespace qot {
+
+template <int H, int D>
+__global__ __launch_bounds__(256) void tconv_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ skip, int ld, const float* __restrict__ ea,
+    const float* __restrict__ we, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, float* __restrict__ out,
+    float* __restrict__ stats, int64_t N) {
+    constexpr int TPR = H / 4;
+    constexpr int RPB = 256 / TPR;
+    const int sub = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    if (i >= N) return;
+    const float rs = rsqrtf((float)H);
+    const int c0 = 4 * sub;
+
+    float4 qi = scale4(rs, ld4(q + i * ld + c0));
+    float wl[4][D];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
+    float qe[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        qe[d] = group_sum<TPR>(qi.x * wl[0][d] + qi.y * wl[1][d] + qi.z * wl[2][d] + qi.w * wl[3][d]);
+
+    float m = -INFINITY, l = 0.f;
+    float4 acc = f4zero();
+    float aacc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) aacc[d] = 0.f;
+
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    for (int p = beg; p < end; ++p) {
+        const int64_t j = col[p];
+        const int64_t e = eid[p];
+        float4 kj = ld4(k + j * ld + c0);
+        float4 vj = ld4(v + j * ld + c0);
+        float ee[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+        float s = group_sum<TPR>(dot4(qi, kj));
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
+        float mn = fmaxf(m, s);
+        float sc = __expf(m - mn);
+        float pe = __expf(s - mn);
+        l = fmaf(l, sc, pe);
+        acc = fma4(pe, vj, scale4(sc, acc));
+#pragma unroll
+        for (int d = 0; d < D; ++d) aacc[d] = fmaf(pe, ee[d], aacc[d] * sc);
+        m = mn;
+    }
+    const float denom = l + 1e-16f;
+    const float inv = 1.0f / denom;
+    float4 o = scale4(inv, acc);
+    float oc[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[c][d], aacc[d] * inv, oc[c]);
+    float4 sk = ld4(skip + i * ld + c0);
+    st4(out + i * H + c0, make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w));
+    if (sub == 0) {
+        stats[2 * i] = (beg < end) ? m : 0.f;
+        stats[2 * i + 1] = denom;
+    }
+}
+
+// Backward, destination pass.  With a_e the attention weight and da_e = <g_i, v_j + We ea_e>:
+//   delta_i = sum_e a_e da_e ;  ds_e = a_e (da_e - delta_i)
+//   grad_q_i = (sum_e ds_e k_j + We sum_e ds_e ea_e)/sqrt(H)
+//            = ((A1 - delta A2) + We (P1 - delta P2))/sqrt(H)
+// with A1 = sum a da k_j, A2 = sum a k_j, P1 = sum a da ea, P2 = sum a ea -- a single
+// sweep over the in-edges, no second gather of k.
+template <int H, int D>
+__global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, int ld, const float* __restrict__ ea,
+    const float* __restrict__ we, const float* __restrict__ stats,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ eid, float* __restrict__ gq, int ld_g, float* __restrict__ escr,
+    float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal, int64_t N) {
+    constexpr int TPR = H / 4;
+    constexpr int RPB = 256 / TPR;
+    const int sub = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    if (i >= N) return;
+    const float rs = rsqrtf((float)H);
+    const int c0 = 4 * sub;
+
+    float4 qi = scale4(rs, ld4(q + i * ld + c0));
+    float4 gi = ld4(g + i * H + c0);
+    float wl[4][D];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
+    float qe[D], ge[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        qe[d] = group_sum<TPR>(qi.x * wl[0][d] + qi.y * wl[1][d] + qi.z * wl[2][d] + qi.w * wl[3][d]);
+        ge[d] = group_sum<TPR>(gi.x * wl[0][d] + gi.y * wl[1][d] + gi.z * wl[2][d] + gi.w * wl[3][d]);
+    }
+    const float m = stats[2 * i];
+    const float inv = 1.0f / stats[2 * i + 1];
+
+    float4 a1 = f4zero(), a2 = f4zero();
+    float p1[D], p2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { p1[d] = 0.f; p2[d] = 0.f; }
+    float sada = 0.f;
+
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    for (int p = beg; p < end; ++p) {
+        const int64_t j = col[p];
+        const int64_t e = eid[p];
+        float4 kj = ld4(k + j * ld + c0);
+        float4 vj = ld4(v + j * ld + c0);
+        float ee[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+        float s = dot4(qi, kj), da = dot4(gi, vj);
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            da += __shfl_xor(da, o);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            s = fmaf(qe[d], ee[d], s);
+            da = fmaf(ge[d], ee[d], da);
+        }
+        const float a = __expf(s - m) * inv;
+        const float ada = a * da;
+        sada += ada;
+        a1 = fma4(ada, kj, a1);
+        a2 = fma4(a, kj, a2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            p1[d] = fmaf(ada, ee[d], p1[d]);
+            p2[d] = fmaf(a, ee[d], p2[d]);
+        }
+        if (sub == 0) {
+            escr[2 * (int64_t)p] = a;
+            escr[2 * (int64_t)p + 1] = da;
+        }
+    }
+    float pd[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) pd[d] = p1[d] - sada * p2[d];
+    float4 r = sub4(a1, scale4(sada, a2));
+    float rc[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) rc[c] = fmaf(wl[c][d], pd[d], rc[c]);
+        rc[c] *= rs;
+    }
+    st4(gq + i * ld_g + c0, make_float4(rc[0], rc[1], rc[2], rc[3]));
+    if (sub == 0) {
+        delta[i] = sada;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            pds[i * D + d] = pd[d];
+            pal[i * D + d] = p2[d];
+        }
+    }
+}
+
+// Backward, source pass over the CSC: grad_v_j = sum_{e: j->i} a_e g_i,
+// grad_k_j = sum_e ds_e q_i / sqrt(H).
+template <int H>
+__global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, int ld,
+    const float* __restrict__ escr, const float* __restrict__ delta,
+    const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
+    const int32_t* __restrict__ pos_t, float* __restrict__ gk, float* __restrict__ gv, int ld_g,
+    int64_t N) {
+    constexpr int TPR = H / 4;
+    constexpr int RPB = 256 / TPR;
+    const int sub = threadIdx.x % TPR;
+    const int64_t j = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    if (j >= N) return;
+    const float rs = rsqrtf((float)H);
+    const int c0 = 4 * sub;
+    float4 ak = f4zero(), av = f4zero();
+    const int beg = rowptr_t[j], end = rowptr_t[j + 1];
+    for (int t = beg; t < end; ++t) {
+        const int64_t i = col_t[t];
+        const int64_t p = pos_t[t];
+        const float a = escr[2 * p], da = escr[2 * p + 1];
+        const float ds = a * (da - delta[i]) * rs;
+        float4 gi = ld4(g + i * H + c0);
+        float4 qi = ld4(q + i * ld + c0);
+        av = fma4(a, gi, av);
+        ak = fma4(ds, qi, ak);
+    }
+    st4(gk + j * ld_g + c0, ak);
+    st4(gv + j * ld_g + c0, av);
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
+                             const float* edge_attr, const float* w_edge, const int32_t* rowptr,
+                             const int32_t* col, const int32_t* eid, float* out, float* stats,
+                             int64_t N, int H, int D, qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!q || !k || !v || !skip || !out || !stats || !w_edge || (ld & 3)) return QOT_ERR_BADARG;
+    QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
+        constexpr int RPB = 256 / (kH / 4);
+        tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
+            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, out, stats, N);
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v,
+                                 int ld, const float* edge_attr, const float* w_edge,
+                                 const float* stats, const int32_t* rowptr, const int32_t* col,
+                                 const int32_t* eid, float* grad_q, int ld_g, float* escr, float* delta,
+                                 float* pds, float* pal, int64_t N, int H, int D, qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!grad_out || !q || !k || !v || !stats || !grad_q || !delta || !pds || !pal || (ld & 3) || (ld_g & 3))
+        return QOT_ERR_BADARG;
+    QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
+        constexpr int RPB = 256 / (kH / 4);
+        tconv_bwd_dst_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
+            grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, grad_q, ld_g, escr,
+            delta, pds, pal, N);
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
+                                 const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
+                                 const int32_t* pos_t, float* grad_k, float* grad_v, int ld_g, int64_t N,
+                                 int H, qot_stream_t stream) {
+    if (N < 0 || !rowptr_t) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!grad_out || !q || !delta || !grad_k || !grad_v || (ld & 3) || (ld_g & 3)) return QOT_ERR_BADARG;
+    QOT_DISPATCH_H(H, {
+        constexpr int RPB = 256 / (kH / 4);
+        tconv_bwd_src_kernel<kH><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
+            grad_out, q, ld, escr, delta, rowptr_t, col_t, pos_t, grad_k, grad_v, ld_g, N);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

@@ -1,0 +1,337 @@
+"""``torch.autograd.Function`` wrappers around the C ABI (``include/qot_gnn.h``).
+
+These own save-for-backward and output allocation (through torch's caching allocator);
+the library itself never allocates.  Dense projections stay ``torch`` GEMMs (rocBLAS /
+hipBLASLt on the matrix cores) -- the north star reserves MFMA for exactly those.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from .graph import GraphIndex, require_cuda
+
+P = _lib.ptr
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("the HIP path computes in fp32; got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _off(t: torch.Tensor, floats: int) -> int:
+    return t.data_ptr() + 4 * floats
+
+
+# ------------------------------------------------------------------ embedding (a1)
+class EmbedFn(torch.autograd.Function):
+    """``table[node_ids]`` -- ``topological_training/models.py:51-52``."""
+
+    @staticmethod
+    def forward(ctx, table, ids32):
+        require_cuda(table, ids32)
+        table = _f32c(table)
+        N, (V, H) = ids32.numel(), table.shape
+        out = torch.empty(N, H, dtype=torch.float32, device=table.device)
+        _lib.call("qot_embed_fwd", P(table), P(ids32), P(out), N, V, H)
+        ctx.save_for_backward(ids32)
+        ctx.vh = (V, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids32,) = ctx.saved_tensors
+        V, H = ctx.vh
+        g = _f32c(g)
+        gt = torch.zeros(V, H, dtype=torch.float32, device=g.device)
+        _lib.call("qot_embed_bwd", P(g), P(ids32), P(gt), ids32.numel(), V, H)
+        return gt, None
+
+
+# ------------------------------------------------------------------ TransformerConv (a2)
+class TConvFn(torch.autograd.Function):
+    """Fused edge-softmax-aggregate of TransformerConv on packed projections.
+
+    ``qkvs`` is ``[N, 4H]`` = ``[q | k | v | skip]`` (one GEMM); returns ``[N, H]``.
+    """
+
+    @staticmethod
+    def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex):
+        require_cuda(qkvs, edge_attr, w_edge)
+        qkvs, edge_attr, w_edge = _f32c(qkvs), _f32c(edge_attr), _f32c(w_edge)
+        N, H4 = qkvs.shape
+        H = H4 // 4
+        D = w_edge.shape[1]
+        if edge_attr.shape != (graph.num_edges_in, D):
+            raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
+        out = torch.empty(N, H, dtype=torch.float32, device=qkvs.device)
+        stats = torch.empty(N, 2, dtype=torch.float32, device=qkvs.device)
+        _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
+                  P(edge_attr), P(w_edge), P(graph.rowptr), P(graph.col), P(graph.eid), P(out), P(stats),
+                  N, H, D)
+        ctx.save_for_backward(qkvs, edge_attr, w_edge, stats)
+        ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkvs, edge_attr, w_edge, stats = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g)
+        N, H4 = qkvs.shape
+        H = H4 // 4
+        D = w_edge.shape[1]
+        dev = qkvs.device
+        gqkvs = torch.empty(N, H4, dtype=torch.float32, device=dev)
+        escr = torch.empty(max(graph.cap, 1), 2, dtype=torch.float32, device=dev)
+        delta = torch.empty(N, dtype=torch.float32, device=dev)
+        pds = torch.empty(N, D, dtype=torch.float32, device=dev)
+        pal = torch.empty(N, D, dtype=torch.float32, device=dev)
+        _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
+                  P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(graph.col), P(graph.eid),
+                  _off(gqkvs, 0), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
+        _lib.call("qot_tconv_bwd_src", P(g), _off(qkvs, 0), H4, P(escr), P(delta), P(graph.rowptr_t),
+                  P(graph.col_t), P(graph.pos_t), _off(gqkvs, H), _off(gqkvs, 2 * H), H4, N, H)
+        gqkvs[:, 3 * H:] = g
+        q = qkvs[:, :H]
+        gwe = torch.addmm(g.t() @ pal, q.t(), pds, alpha=1.0 / math.sqrt(H))
+        return gqkvs, None, gwe, None
+
+
+# ------------------------------------------------------------------ NNConv (a4)
+def nnconv_wcat(w2, b2, wroot, hin, hout, k):
+    """[(K+2)*Hin, Hout]: K blocks of the edge-MLP's second layer, its bias block, root^T."""
+    return torch.cat([
+        w2.view(hin, hout, k).permute(2, 0, 1).reshape(k * hin, hout),
+        b2.view(hin, hout),
+        wroot.t(),
+    ], dim=0)
+
+
+def nnconv_wcat_t(w2, b2, wroot, hin, hout, k):
+    """[(K+2)*Hout, Hin]: the per-block transposes (adjoint GEMM operand)."""
+    return torch.cat([
+        w2.view(hin, hout, k).permute(2, 1, 0).reshape(k * hout, hin),
+        b2.view(hin, hout).t(),
+        wroot,
+    ], dim=0)
+
+
+class NNConvFn(torch.autograd.Function):
+    """NNConv(aggr='mean') = aggregate-then-GEMM (see ``csrc/nnconv.hip``)."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex):
+        require_cuda(x, edge_attr, w1, b1, w2, b2, wroot, bias)
+        x, edge_attr = _f32c(x), _f32c(edge_attr)
+        w1, b1, w2, b2, wroot, bias = (_f32c(t) for t in (w1, b1, w2, b2, wroot, bias))
+        N, hin = x.shape
+        hout = wroot.shape[0]
+        K, D = w1.shape
+        if K != 2 * D:
+            raise _lib.QotError("NNConv edge MLP must be Linear(D, 2D) -> ReLU -> Linear(2D, Hin*Hout)")
+        if edge_attr.shape != (graph.num_edges_in, D):
+            raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
+        A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
+        _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                  P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
+        out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A)
+        ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, edge_attr, w1, b1, w2, b2, wroot, A = ctx.saved_tensors
+        graph = ctx.graph
+        g = _f32c(g)
+        N, hin = x.shape
+        hout = wroot.shape[0]
+        K, D = w1.shape
+        dev = x.device
+        gbias = g.sum(0)
+        gwcat = A.t() @ g                                        # [(K+2)Hin, Hout]
+        gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
+        gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
+        gwroot = gwcat[(K + 1) * hin:].t()
+        # grad_x: same aggregation over the transposed graph, then one GEMM
+        U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
+        _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                  P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
+        gx = U @ nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        # grad of the edge MLP's first layer
+        wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
+        GA = g @ wk.t()                                          # [N, K*Hin]
+        gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
+        gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
+        if hin != hout:
+            raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
+        _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
+                  P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None
+
+
+# ------------------------------------------------------------------ leaky_relu + dropout (a3)
+class ActFn(torch.autograd.Function):
+    """``dropout(leaky_relu(x, slope), p)`` in one pass; mask regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, slope, p, seed, step_counter):
+        require_cuda(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _lib.call("qot_act_fwd", P(x), P(y), x.numel(), float(slope), float(p), int(seed), P(step_counter))
+        ctx.save_for_backward(y, step_counter if step_counter is not None else torch.empty(0))
+        ctx.cfg = (float(slope), float(p), int(seed), step_counter is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, counter = ctx.saved_tensors
+        slope, p, seed, has_counter = ctx.cfg
+        g = _f32c(g)
+        gx = torch.empty_like(g)
+        _lib.call("qot_act_bwd", P(g), P(y), P(gx), g.numel(), slope, p, seed, P(counter) if has_counter else None)
+        return gx, None, None, None, None
+
+
+# ------------------------------------------------------------------ global mean pool (a5)
+class PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, batch32, ptr32, B):
+        require_cuda(x)
+        x = _f32c(x)
+        N, H = x.shape
+        out = torch.empty(B, H, dtype=torch.float32, device=x.device)
+        _lib.call("qot_pool_fwd", P(x), P(ptr32), P(out), B, H)
+        ctx.save_for_backward(batch32, ptr32)
+        ctx.dims = (N, H, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        batch32, ptr32 = ctx.saved_tensors
+        N, H, B = ctx.dims
+        g = _f32c(g)
+        gx = torch.empty(N, H, dtype=torch.float32, device=g.device)
+        _lib.call("qot_pool_bwd", P(g), P(ptr32), P(batch32), P(gx), N, B, H)
+        return gx, None, None, None
+
+
+# ------------------------------------------------------------------ GATConv (a7)
+class GatFn(torch.autograd.Function):
+    """Fused GAT edge softmax + aggregation (+bias).  ``graph`` carries the self loops."""
+
+    @staticmethod
+    def forward(ctx, z, a_src, a_dst, bias, graph: GraphIndex, neg_slope: float):
+        require_cuda(z, a_src, a_dst, bias)
+        z, a_src, a_dst, bias = _f32c(z), _f32c(a_src), _f32c(a_dst), _f32c(bias)
+        N, HC = z.shape
+        heads = a_src.shape[1]
+        C = HC // heads
+        out = torch.empty(N, HC, dtype=torch.float32, device=z.device)
+        stats = torch.empty(N, heads, 2, dtype=torch.float32, device=z.device)
+        _lib.call("qot_gat_fwd", P(z), P(a_src), P(a_dst), P(bias), P(graph.rowptr), P(graph.col), P(out),
+                  P(stats), N, heads, C, float(neg_slope))
+        ctx.save_for_backward(z, a_src, a_dst, stats)
+        ctx.graph, ctx.ns = graph, float(neg_slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, a_src, a_dst, stats = ctx.saved_tensors
+        graph, ns = ctx.graph, ctx.ns
+        g = _f32c(g)
+        N, HC = z.shape
+        heads = a_src.shape[1]
+        C = HC // heads
+        dev = z.device
+        gad = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        gas = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        gz = torch.empty(N, HC, dtype=torch.float32, device=dev)
+        escr = torch.empty(max(graph.cap, 1), heads, 2, dtype=torch.float32, device=dev)
+        delta = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        _lib.call("qot_gat_bwd_dst", P(g), P(z), P(a_src), P(a_dst), P(stats), P(graph.rowptr), P(graph.col),
+                  P(gad), P(escr), P(delta), N, heads, C, ns)
+        _lib.call("qot_gat_bwd_src", P(g), P(a_src), P(a_dst), P(escr), P(delta), P(graph.rowptr_t),
+                  P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns)
+        return gz, gas, gad, g.sum(0), None, None
+
+
+# ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)
+class BnFn(torch.autograd.Function):
+    """BatchNorm1d over the node matrix with an optional fused ReLU.
+
+    Training: batch statistics + in-place running-stat update (momentum, unbiased var).
+    Eval: running statistics.  App. B.4.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        require_cuda(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, C = x.shape
+        dev = x.device
+        if training:
+            if N == 0:
+                raise ValueError("BatchNorm in training mode needs at least one row")
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+            _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),
+                      P(running_mean), P(running_var), P(part))
+        else:
+            mean = running_mean.detach().to(torch.float32).contiguous()
+            rstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
+        y = torch.empty_like(x)
+        _lib.call("qot_bn_apply", P(x), P(mean), P(rstd), P(weight), P(bias), P(y), N, C, int(relu))
+        ctx.save_for_backward(x, y, mean, rstd, weight)
+        ctx.cfg = (bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mean, rstd, weight = ctx.saved_tensors
+        training, relu = ctx.cfg
+        g = _f32c(g)
+        N, C = x.shape
+        dev = x.device
+        gw = torch.empty(C, dtype=torch.float32, device=dev)
+        gb = torch.empty(C, dtype=torch.float32, device=dev)
+        gx = torch.empty_like(x)
+        if N > 0:
+            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+            _lib.call("qot_bn_bwd_reduce", P(g), P(y), P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
+                      P(part))
+            _lib.call("qot_bn_bwd_apply", P(g), P(y), P(x), P(mean), P(rstd), P(weight), P(gw), P(gb), P(gx),
+                      N, C, int(relu), int(training))
+        else:
+            gw.zero_(); gb.zero_()
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------ LUT rows (a9)
+class RowsGatherFn(torch.autograd.Function):
+    """``x[idx]`` for a unique index list (boolean-mask selection) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, idx32):
+        require_cuda(x, idx32)
+        x = _f32c(x)
+        n, C = idx32.numel(), x.shape[1]
+        out = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        _lib.call("qot_rows_gather", P(x), P(idx32), P(out), n, C)
+        ctx.save_for_backward(idx32)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx32,) = ctx.saved_tensors
+        g = _f32c(g)
+        gx = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _lib.call("qot_rows_scatter", P(g), P(idx32), P(gx), idx32.numel(), ctx.shape[1])
+        return gx, None

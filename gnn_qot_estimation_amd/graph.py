@@ -1,0 +1,142 @@
+"""Device-side graph index (CSR by destination + CSC by source), built once per batch.
+
+The reference re-derives this bookkeeping inside every PyG conv call
+(``topological_training/models.py:53,57``; ``lightpath_training/models.py:30`` also rebuilds
+the self-loop edge list each call).  Topology is static across layers and across
+forward/backward, so the index is cached on the batch object.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class GraphIndex:
+    num_nodes: int
+    num_edges_in: int      # E of the caller's edge_index
+    cap: int               # slots allocated (E, or E + N with GAT self loops)
+    rowptr: torch.Tensor   # [N+1] int32, in-edges of node i are slots rowptr[i]:rowptr[i+1]
+    col: torch.Tensor      # [cap] int32 source node of each slot
+    eid: torch.Tensor      # [cap] int32 original edge id (-1 = inserted self loop)
+    row: torch.Tensor      # [cap] int32 destination of each slot
+    rowptr_t: torch.Tensor  # [N+1] int32, out-edges of node j
+    col_t: torch.Tensor    # [cap] int32 destination of each out-edge
+    pos_t: torch.Tensor    # [cap] int32 CSR slot of each out-edge
+    invdeg: torch.Tensor   # [N] fp32 1/max(in_degree,1)
+    gat_self_loops: bool
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.QotError(
+                "the HIP message-passing path needs CUDA (ROCm) tensors; got a CPU tensor. "
+                "There is no CPU fallback -- move the model and batch to the GPU."
+            )
+
+
+def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False) -> GraphIndex:
+    require_cuda(edge_index)
+    if edge_index.dtype != torch.long or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must be int64 [2, E]")
+    ei = edge_index.contiguous()
+    dev = ei.device
+    E = ei.shape[1]
+    N = int(num_nodes)
+    cap = E + (N if gat_self_loops else 0)
+    i32 = dict(dtype=torch.int32, device=dev)
+    g = GraphIndex(
+        num_nodes=N, num_edges_in=E, cap=cap,
+        rowptr=torch.empty(N + 1, **i32), col=torch.empty(max(cap, 1), **i32),
+        eid=torch.empty(max(cap, 1), **i32), row=torch.empty(max(cap, 1), **i32),
+        rowptr_t=torch.empty(N + 1, **i32), col_t=torch.empty(max(cap, 1), **i32),
+        pos_t=torch.empty(max(cap, 1), **i32),
+        invdeg=torch.empty(max(N, 1), dtype=torch.float32, device=dev),
+        gat_self_loops=gat_self_loops,
+    )
+    lib = _lib.load()
+    ws_bytes = lib.qot_csr_workspace_bytes(E, N, int(gat_self_loops))
+    if ws_bytes == 0:
+        raise _lib.QotError("qot_csr_workspace_bytes failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call("qot_csr_build", _lib.ptr(ei), E, N, int(gat_self_loops), _lib.ptr(g.rowptr), _lib.ptr(g.col),
+              _lib.ptr(g.eid), _lib.ptr(g.row), _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t), _lib.ptr(g.pos_t),
+              _lib.ptr(g.invdeg), _lib.ptr(ws), ws_bytes)
+    return g
+
+
+def _cache(data) -> Optional[dict]:
+    c = getattr(data, "_qot_cache", None)
+    if c is None:
+        c = {}
+        try:
+            setattr(data, "_qot_cache", c)
+        except Exception:
+            return None
+    return c
+
+
+def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> GraphIndex:
+    """Cached ``GraphIndex`` of ``data.edge_index`` (rebuilt if the tensor changed)."""
+    ei = data.edge_index
+    key = ("graph", bool(gat_self_loops))
+    tag = (ei.data_ptr(), ei._version, tuple(ei.shape), int(num_nodes))
+    c = _cache(data)
+    if c is not None and key in c and c[key][0] == tag:
+        return c[key][1]
+    g = build_graph_index(ei, num_nodes, gat_self_loops)
+    if c is not None:
+        c[key] = (tag, g)
+    return g
+
+
+def to_i32(t: torch.Tensor) -> torch.Tensor:
+    require_cuda(t)
+    t = t.contiguous()
+    if t.dtype == torch.int32:
+        return t
+    if t.dtype != torch.long:
+        raise ValueError("expected an int64 index tensor")
+    out = torch.empty(t.shape, dtype=torch.int32, device=t.device)
+    _lib.call("qot_i64_to_i32", _lib.ptr(t), _lib.ptr(out), t.numel())
+    return out
+
+
+def batch_index_for(data, num_nodes: int):
+    """(batch32 [N], ptr32 [B+1], B).  ``B`` comes from ``data.num_graphs`` when the batch
+    object carries it; otherwise ``batch.max()+1`` as PyG's global_mean_pool does
+    (``topological_training/models.py:61``) -- that one costs a device sync."""
+    batch = data.batch
+    tag = (batch.data_ptr(), batch._version, tuple(batch.shape))
+    c = _cache(data)
+    if c is not None and "batch" in c and c["batch"][0] == tag:
+        return c["batch"][1]
+    B = getattr(data, "num_graphs", None)
+    if B is None:
+        B = int(batch.max().item()) + 1 if batch.numel() else 0
+    B = int(B)
+    b32 = to_i32(batch)
+    ptr = torch.empty(B + 1, dtype=torch.int32, device=batch.device)
+    _lib.call("qot_batch_ptr", _lib.ptr(b32), int(num_nodes), B, _lib.ptr(ptr))
+    res = (b32, ptr, B)
+    if c is not None:
+        c["batch"] = (tag, res)
+    return res
+
+
+def cached_i32(data, name: str) -> torch.Tensor:
+    t = getattr(data, name)
+    tag = (t.data_ptr(), t._version, tuple(t.shape))
+    c = _cache(data)
+    key = ("i32", name)
+    if c is not None and key in c and c[key][0] == tag:
+        return c[key][1]
+    out = to_i32(t)
+    if c is not None:
+        c[key] = (tag, out)
+    return out

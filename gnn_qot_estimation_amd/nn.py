@@ -1,0 +1,172 @@
+"""Operator modules with the constructor surface, ``forward`` signatures and ``state_dict``
+keys of the torch_geometric classes the reference imports
+(``topological_training/models.py:3``: ``global_mean_pool, TransformerConv, NNConv``;
+``lightpath_training/models.py:3``: ``GATConv, BatchNorm``) -- SURVEY.md Appendix A/B.
+
+Only the configurations the reference instantiates are implemented (heads=1 concat
+TransformerConv with ``edge_dim``; NNConv ``aggr="mean"``; GATConv ``heads=4, concat=True``);
+anything else raises ``NotImplementedError`` rather than silently computing something else.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import functional as QF
+from .graph import GraphIndex, batch_index_for, build_graph_index
+
+
+def _pyg_linear_init(lin: nn.Linear):
+    nn.init.kaiming_uniform_(lin.weight, a=math.sqrt(5))
+    if lin.bias is not None:
+        bound = 1.0 / math.sqrt(lin.weight.shape[1])
+        nn.init.uniform_(lin.bias, -bound, bound)
+
+
+class TransformerConv(nn.Module):
+    """``TransformerConv(in, out, edge_dim=D)`` (heads=1, concat, root_weight, beta=False)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 beta: bool = False, dropout: float = 0.0, edge_dim: Optional[int] = None,
+                 bias: bool = True, root_weight: bool = True):
+        super().__init__()
+        if heads != 1 or not concat or beta or dropout != 0.0 or edge_dim is None or not bias or not root_weight:
+            raise NotImplementedError("only the reference's TransformerConv(H, H, edge_dim=D) configuration")
+        self.in_channels, self.out_channels, self.edge_dim = in_channels, out_channels, edge_dim
+        self.lin_key = nn.Linear(in_channels, out_channels)
+        self.lin_query = nn.Linear(in_channels, out_channels)
+        self.lin_value = nn.Linear(in_channels, out_channels)
+        self.lin_edge = nn.Linear(edge_dim, out_channels, bias=False)
+        self.lin_skip = nn.Linear(in_channels, out_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.lin_key, self.lin_query, self.lin_value, self.lin_edge, self.lin_skip):
+            _pyg_linear_init(m)
+
+    def packed_weight(self):
+        w = torch.cat([self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight], 0)
+        b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], 0)
+        return w, b
+
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None):
+        if graph is None:
+            graph = build_graph_index(edge_index, x.shape[0])
+        w, b = self.packed_weight()
+        qkvs = F.linear(x, w, b)                      # one MFMA GEMM for q|k|v|skip
+        return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph)
+
+
+class NNConv(nn.Module):
+    """``NNConv(in, out, nn=Seq(Linear(D,2D), ReLU, Linear(2D,in*out)), aggr="mean")``."""
+
+    def __init__(self, in_channels: int, out_channels: int, nn: nn.Module, aggr: str = "add",
+                 root_weight: bool = True, bias: bool = True):
+        super().__init__()
+        if aggr != "mean" or not root_weight or not bias:
+            raise NotImplementedError("only the reference's NNConv(aggr='mean', root_weight, bias)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.nn = nn
+        self.lin = torch.nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.in_channels)
+        torch.nn.init.uniform_(self.lin.weight, -bound, bound)
+        torch.nn.init.zeros_(self.bias)
+
+    def _edge_mlp(self):
+        seq = self.nn
+        ok = (isinstance(seq, torch.nn.Sequential) and len(seq) == 3 and isinstance(seq[0], torch.nn.Linear)
+              and isinstance(seq[1], torch.nn.ReLU) and isinstance(seq[2], torch.nn.Linear)
+              and seq[2].out_features == self.in_channels * self.out_channels
+              and seq[0].bias is not None and seq[2].bias is not None)
+        if not ok:
+            raise NotImplementedError("edge network must be Seq(Linear, ReLU, Linear(., in*out)) as in "
+                                      "topological_training/models.py:20-24")
+        return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
+
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None):
+        if graph is None:
+            graph = build_graph_index(edge_index, x.shape[0])
+        w1, b1, w2, b2 = self._edge_mlp()
+        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph)
+
+
+class GATConv(nn.Module):
+    """``GATConv(in, out, heads=4, concat=True)`` (negative_slope 0.2, self loops, bias)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, dropout: float = 0.0, add_self_loops: bool = True,
+                 edge_dim: Optional[int] = None, bias: bool = True):
+        super().__init__()
+        if not concat or dropout != 0.0 or not add_self_loops or edge_dim is not None or not bias:
+            raise NotImplementedError("only the reference's GATConv(F, C, heads=4, concat=True) configuration")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.negative_slope = negative_slope
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(heads * out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.lin.weight)
+        for a in (self.att_src, self.att_dst):
+            stdv = math.sqrt(6.0 / (a.size(-2) + a.size(-1)))
+            nn.init.uniform_(a, -stdv, stdv)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index, graph: Optional[GraphIndex] = None):
+        n, h, c = x.shape[0], self.heads, self.out_channels
+        if graph is None:
+            graph = build_graph_index(edge_index, n, gat_self_loops=True)
+        if not graph.gat_self_loops:
+            raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
+        z = self.lin(x)
+        zv = z.view(n, h, c)
+        a_src = (zv * self.att_src).sum(-1)
+        a_dst = (zv * self.att_dst).sum(-1)
+        return QF.GatFn.apply(z, a_src, a_dst, self.bias, graph, self.negative_slope)
+
+
+class BatchNorm(nn.Module):
+    """PyG ``BatchNorm``: wraps ``BatchNorm1d`` as ``.module`` (keys ``<name>.module.*``)."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5, momentum: float = 0.1, affine: bool = True,
+                 track_running_stats: bool = True):
+        super().__init__()
+        if not affine or not track_running_stats or momentum is None:
+            raise NotImplementedError("only affine BatchNorm with running statistics")
+        self.module = nn.BatchNorm1d(in_channels, eps=eps, momentum=momentum)
+
+    def forward(self, x, relu: bool = False):
+        m = self.module
+        if self.training:
+            m.num_batches_tracked.add_(1)
+        return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
+                             m.momentum, m.eps, relu)
+
+
+def global_mean_pool(x, batch, size: Optional[int] = None, data=None):
+    """``global_mean_pool(x, batch)`` -- ``topological_training/models.py:61``.
+
+    With only ``(x, batch)`` the graph count is ``batch.max()+1`` exactly as PyG computes
+    it (one device sync); pass ``size`` or the batch object to avoid the sync.
+    """
+    if data is not None and getattr(data, "batch", None) is batch:
+        b32, ptr, B = batch_index_for(data, x.shape[0])
+    else:
+        class _Tmp:
+            pass
+        t = _Tmp()
+        t.batch = batch
+        if size is not None:
+            t.num_graphs = int(size)
+        b32, ptr, B = batch_index_for(t, x.shape[0])
+    return QF.PoolFn.apply(x, b32, ptr, B)

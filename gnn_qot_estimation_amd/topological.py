@@ -1,0 +1,73 @@
+"""``TopologicalGNN`` on the HIP message-passing engine.
+
+Same constructor, ``forward(data)`` contract and ``state_dict`` keys as
+``topological_training/models.py:6-64`` of the reference, so
+``train.py``/``test.py`` and the shipped ``models/model_0.pth`` work unchanged.  The conv
+layers run through ``libqot_gnn.so``; there is no PyG and no CPU fallback.
+
+``num_layers`` is a build extension (default 2 = the reference): every layer beyond the
+second is another NNConv with its own edge network (``conv3.*``, ...), used by the
+3-layer benchmark configurations.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import functional as QF
+from .graph import batch_index_for, cached_i32, graph_index_for
+from .nn import NNConv, TransformerConv
+
+
+class TopologicalGNN(nn.Module):
+    def __init__(self, num_nodes, hidden_channels, out_channels, edge_dim, dropout_p=0.5, num_layers=2):
+        super().__init__()
+        if num_layers < 2:
+            raise ValueError("num_layers >= 2 (TransformerConv + NNConv is the reference model)")
+        self.node_embeddings = nn.Embedding(num_nodes, hidden_channels)
+        self.conv1 = TransformerConv(hidden_channels, hidden_channels, edge_dim=edge_dim)
+        for layer in range(2, num_layers + 1):
+            edge_nn = nn.Sequential(
+                nn.Linear(edge_dim, edge_dim * 2),
+                nn.ReLU(),
+                nn.Linear(edge_dim * 2, hidden_channels * hidden_channels),
+            )
+            setattr(self, f"conv{layer}", NNConv(hidden_channels, hidden_channels, nn=edge_nn, aggr="mean"))
+        self.mlp = nn.Sequential(
+            nn.Linear(hidden_channels, hidden_channels),
+            nn.LeakyReLU(),
+            nn.Dropout(p=dropout_p),
+            nn.Linear(hidden_channels, out_channels),
+        )
+        self.dropout = nn.Dropout(p=dropout_p)
+        self.num_layers = num_layers
+        # dropout RNG state of the fused activation kernels (not part of state_dict)
+        self.register_buffer("_qot_step", torch.zeros((), dtype=torch.long), persistent=False)
+        self._qot_seed = None
+
+    def _act(self, x, site: int, step):
+        """leaky_relu(0.01) + Dropout(p) of models.py:54-55 / 58-59 as one kernel."""
+        p = self.dropout.p if self.training else 0.0
+        if self._qot_seed is None:
+            self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        seed = (self._qot_seed + 0x9E3779B97F4A7C15 * (site + 1)) & 0xFFFFFFFFFFFFFFFF
+        return QF.ActFn.apply(x, 0.01, p, seed, step if p > 0.0 else None)
+
+    def forward(self, data):
+        x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        if x is None or x.numel() == 0:
+            n = data.node_ids.shape[0]
+            x = QF.EmbedFn.apply(self.node_embeddings.weight, cached_i32(data, "node_ids"))
+        else:
+            n = x.shape[0]
+        graph = graph_index_for(data, n)
+        step = None
+        if self.training and self.dropout.p > 0.0:
+            self._qot_step.add_(1)
+            step = self._qot_step.clone()   # this forward's draw; backward re-reads the clone
+        x = self._act(self.conv1(x, edge_index, edge_attr, graph=graph), 0, step)
+        for layer in range(2, self.num_layers + 1):
+            x = self._act(getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph), layer - 1, step)
+        b32, ptr, B = batch_index_for(data, n)
+        x = QF.PoolFn.apply(x, b32, ptr, B)
+        return self.mlp(x)

@@ -1,0 +1,193 @@
+/*
+ * qot_gnn.h -- C ABI of libqot_gnn.so, the MI355X (gfx950) message-passing engine that
+ * replaces the torch_geometric operator layer under the reference's two models.
+ *
+ * Reference interface each entry point replaces (paths relative to the reference repo;
+ * [PyG-ext] = third-party torch_geometric code reached from that line):
+ *
+ *   qot_csr_build            edge_index handling inside every conv call:
+ *                            topological_training/models.py:53,57 and
+ *                            lightpath_training/models.py:30 ([PyG-ext] propagate's
+ *                            index_select/scatter bookkeeping; GATConv's
+ *                            remove_self_loops + add_self_loops)
+ *   qot_embed_{fwd,bwd}      topological_training/models.py:12,51-52  (nn.Embedding lookup)
+ *   qot_tconv_*              topological_training/models.py:15-17,53 ([PyG-ext] TransformerConv)
+ *   qot_nnconv_*             topological_training/models.py:20-30,57 ([PyG-ext] NNConv aggr="mean")
+ *   qot_act_{fwd,bwd}        topological_training/models.py:54-55,58-59 (leaky_relu + Dropout)
+ *   qot_pool_{fwd,bwd}       topological_training/models.py:61 ([PyG-ext] global_mean_pool)
+ *   qot_gat_*                lightpath_training/models.py:13,30 ([PyG-ext] GATConv heads=4)
+ *   qot_bn_*                 lightpath_training/models.py:14,31-32 ([PyG-ext] BatchNorm + relu)
+ *   qot_rows_gather/scatter  lightpath_training/models.py:39-40 (x[lut_mask] and its adjoint)
+ *
+ * Conventions
+ *   - Stateless and stream-ordered: every call only enqueues work on `stream`
+ *     (a hipStream_t passed as void*); the library never allocates, frees or synchronises.
+ *     All outputs and workspaces are caller-allocated DEVICE memory.
+ *   - Return value: 0 = ok; >0 = hipError_t of the failed launch/runtime call;
+ *     <0 = QOT_ERR_* argument error.  qot_error_string() describes either.
+ *   - Feature matrices are row-major fp32.  `ld` arguments are row strides in floats, so a
+ *     packed [N, 4H] projection output can be passed as four column slices.
+ *   - Indices inside the library are int32 (N, E < 2^31); the int64 edge_index of the
+ *     reference contract is consumed only by qot_csr_build.
+ *   - Supported widths: H (and heads*C) power of two in [16, 256] (heads*C up to 1024),
+ *     edge_dim D in {1..8}.  Anything else returns QOT_ERR_UNSUPPORTED (callers must fail
+ *     loudly; there is no CPU fallback).
+ */
+#ifndef QOT_GNN_H
+#define QOT_GNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* qot_stream_t; /* hipStream_t */
+
+#define QOT_ABI_VERSION 1
+#define QOT_OK 0
+#define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
+#define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
+
+int qot_abi_version(void);
+const char* qot_error_string(int code);
+
+/* ---- graph preparation ------------------------------------------------------------
+ * Builds, from edge_index[2,E] (int64, row 0 = source j, row 1 = target i):
+ *   CSR by destination : rowptr[N+1], col[cap] (source of each in-edge), eid[cap]
+ *                        (original edge id, or -1 for an inserted self loop), row[cap]
+ *                        (destination of each CSR slot)
+ *   CSC by source      : rowptr_t[N+1], col_t[cap] (destination of each out-edge),
+ *                        pos_t[cap] (CSR slot of that edge)
+ * cap = E (+ N when gat_self_loops).  Edge order inside a destination follows the
+ * original edge order (stable), so results are run-to-run bitwise reproducible.
+ * gat_self_loops != 0: edges with j == i are dropped and one (n,n) edge per node is
+ * appended (GATConv semantics); the live edge count is rowptr[N] (device side).
+ * invdeg[N] = 1 / max(in_degree, 1).
+ */
+size_t qot_csr_workspace_bytes(int64_t E, int64_t N, int gat_self_loops);
+int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_loops,
+                  int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
+                  int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, float* invdeg,
+                  void* workspace, size_t workspace_bytes, qot_stream_t stream);
+/* int64 -> int32 narrowing of node_ids / batch vectors */
+int qot_i64_to_i32(const int64_t* in, int32_t* out, int64_t n, qot_stream_t stream);
+/* ptr[B+1] from a sorted batch vector */
+int qot_batch_ptr(const int32_t* batch, int64_t N, int64_t B, int32_t* ptr, qot_stream_t stream);
+
+/* ---- embedding -------------------------------------------------------------------- */
+int qot_embed_fwd(const float* table, const int32_t* ids, float* out, int64_t N, int V, int H,
+                  qot_stream_t stream);
+/* grad_table must be zero-filled by the caller; accumulates with per-workgroup LDS
+ * pre-reduction then float atomics. */
+int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, int64_t N, int V,
+                  int H, qot_stream_t stream);
+
+/* ---- TransformerConv (heads=1) ----------------------------------------------------
+ * fwd: out_i = sum_e softmax_e(<q_i, k_j + We ea_e>/sqrt(H)) (v_j + We ea_e) + skip_i
+ * stats[N,2] = (max logit, denominator incl. 1e-16) saved for backward.
+ * edge_attr is in ORIGINAL edge order ([E,D]); the kernels index it through eid.
+ */
+int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
+                  const float* edge_attr, const float* w_edge, const int32_t* rowptr,
+                  const int32_t* col, const int32_t* eid, float* out, float* stats, int64_t N,
+                  int H, int D, qot_stream_t stream);
+/* bwd, destination pass: grad_q[N,H] (ld_g), per-edge scratch escr[cap,2] = (alpha, dalpha),
+ * delta[N], pds[N,D] = sum_e ds_e ea_e, pal[N,D] = sum_e alpha_e ea_e. */
+int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
+                      const float* edge_attr, const float* w_edge, const float* stats,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, float* grad_q,
+                      int ld_g, float* escr, float* delta, float* pds, float* pal, int64_t N, int H,
+                      int D, qot_stream_t stream);
+/* bwd, source pass: grad_k, grad_v [N,H] (ld_g). */
+int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
+                      const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
+                      const int32_t* pos_t, float* grad_k, float* grad_v, int ld_g, int64_t N, int H,
+                      qot_stream_t stream);
+
+/* ---- NNConv (aggr = mean), factorised ----------------------------------------------
+ * h_e = relu(W1 ea_e + b1) in R^K, K = 2D.  Builds the GEMM operand
+ *   A[i] = [ invdeg_i * sum_e h_e[0] x_j | ... | invdeg_i * sum_e h_e[K-1] x_j |
+ *            invdeg_i * sum_e x_j | x_i ]                       ([N, (K+2) H])
+ * so that NNConv(x) = A @ Wcat + bias with Wcat = [W2 blocks; b2 block; W_root^T].
+ * transpose != 0 runs the same aggregation over the CSC (out-edges) with the scale taken
+ * at the gathered end (invdeg[col]) -- the adjoint used for grad_x.
+ */
+int qot_nnconv_agg(const float* x, int ld_x, const float* edge_attr, const float* w1,
+                   const float* b1, const int32_t* rowptr, const int32_t* col,
+                   const int32_t* eid_or_pos, const int32_t* eid_of_pos, const float* invdeg,
+                   int transpose, float* A, int64_t N, int H, int D, qot_stream_t stream);
+/* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
+ * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
+int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,
+                        const float* edge_attr, const float* w1, const float* b1,
+                        const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                        const float* invdeg, float* gw1, float* gb1, int64_t N, int H, int D,
+                        qot_stream_t stream);
+
+/* ---- activation: y = dropout(leaky_relu(x, slope), p) ------------------------------
+ * Counter-based RNG: keep = hash(seed, *step_counter, element) >= p.  step_counter is a
+ * DEVICE int64 the caller bumps once per train step (graph-replay safe).  p == 0 or
+ * step_counter == NULL disables dropout.  bwd regenerates the mask from the same inputs.
+ */
+int qot_act_fwd(const float* x, float* y, int64_t n, float slope, float p, uint64_t seed,
+                const int64_t* step_counter, qot_stream_t stream);
+int qot_act_bwd(const float* grad_y, const float* y_or_x, float* grad_x, int64_t n, float slope,
+                float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream);
+
+/* ---- global mean pool -------------------------------------------------------------- */
+int qot_pool_fwd(const float* x, const int32_t* ptr, float* out, int64_t B, int H,
+                 qot_stream_t stream);
+int qot_pool_bwd(const float* grad_out, const int32_t* ptr, const int32_t* batch, float* grad_x,
+                 int64_t N, int64_t B, int H, qot_stream_t stream);
+
+/* ---- GATConv (concat heads) ---------------------------------------------------------
+ * z[N, heads*C], a_src/a_dst[N, heads]; graph = CSR built with gat_self_loops.
+ * out[N, heads*C] (+bias fused); stats[N, heads, 2]. */
+int qot_gat_fwd(const float* z, const float* a_src, const float* a_dst, const float* bias,
+                const int32_t* rowptr, const int32_t* col, float* out, float* stats, int64_t N,
+                int heads, int C, float neg_slope, qot_stream_t stream);
+/* destination pass: grad_a_dst[N,heads], escr[cap, heads, 2] = (alpha, dalpha), delta[N,heads] */
+int qot_gat_bwd_dst(const float* grad_out, const float* z, const float* a_src, const float* a_dst,
+                    const float* stats, const int32_t* rowptr, const int32_t* col, float* grad_a_dst,
+                    float* escr, float* delta, int64_t N, int heads, int C, float neg_slope,
+                    qot_stream_t stream);
+/* source pass: grad_z[N, heads*C], grad_a_src[N, heads] */
+int qot_gat_bwd_src(const float* grad_out, const float* a_src, const float* a_dst, const float* escr,
+                    const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
+                    const int32_t* pos_t, float* grad_z, float* grad_a_src, int64_t N, int heads,
+                    int C, float neg_slope, qot_stream_t stream);
+
+/* ---- BatchNorm1d (+ fused ReLU) over the node matrix [N, C] -------------------------
+ * qot_bn_stats: mean[C], rstd[C] (biased var, eps), and when running_* != NULL the
+ * momentum update with the unbiased variance.  partials: workspace of
+ * qot_bn_partials_floats(N, C) floats. */
+size_t qot_bn_partials_floats(int64_t N, int C);
+int qot_bn_stats(const float* x, int64_t N, int C, float eps, float momentum, float* mean,
+                 float* rstd, float* running_mean, float* running_var, float* partials,
+                 qot_stream_t stream);
+/* y = relu?((x - mean) * rstd * w + b) */
+int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
+                 const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream);
+/* train-mode backward: needs column sums first (qot_bn_bwd_reduce -> gw[C], gb[C]), then
+ * qot_bn_bwd_apply.  eval mode (batch_stats == 0) skips the mean-subtraction terms. */
+int qot_bn_bwd_reduce(const float* grad_y, const float* y, const float* x, const float* mean,
+                      const float* rstd, float* gw, float* gb, int64_t N, int C, int relu,
+                      float* partials, qot_stream_t stream);
+int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const float* mean,
+                     const float* rstd, const float* w, const float* gw, const float* gb,
+                     float* grad_x, int64_t N, int C, int relu, int batch_stats,
+                     qot_stream_t stream);
+
+/* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
+int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,
+                    qot_stream_t stream);
+/* grad_x must be zero-filled; idx values are unique (a boolean-mask selection) */
+int qot_rows_scatter(const float* grad_out, const int32_t* idx, float* grad_x, int64_t n_idx, int C,
+                     qot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QOT_GNN_H */
