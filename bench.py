@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Headline benchmark: graphs/sec of a full TopologicalGNN train step on MI355X.
+
+Workload (BASELINE.json configs[1]): 2-layer GNN (TransformerConv + NNConv),
+hidden=64, synthetic 100-node / 400-directed-edge topologies, batch=1024 graphs PER GPU
+(weak scaling), fp32, dropout p=0.5 on, SGD(lr .1, momentum .9), SmoothL1 loss.
+One "step" = {CSR build, zero_grad, forward, loss, backward, (gradient all-reduce), SGD}
+-- the body of topological_training/train.py:109-116 -- with the batch resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant hand-written kernel, timed
+live with events on the launch stream; ``cpu_baseline`` is the oracle's PyG-style CPU step
+(kind "port": torch_geometric itself is not installable here) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_*_f32)
+
+CFG = dict(cfg=2, B=1024, n=100, e=400, H=64, D=4, out=3, layers=2, dropout=0.5)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--cpu-sample-graphs", type=int, default=64)
+    return ap.parse_args()
+
+
+def make_batch(rank, device, B=None):
+    from gnn_qot_estimation_amd import synthetic as S
+    B = B or CFG["B"]
+    # 128 distinct graphs per rank, tiled to B (generation is host-side Python; the kernels
+    # see B independent graphs either way)
+    distinct = min(B, 128)
+    base = S.topological_batch(CFG["cfg"], distinct, n=CFG["n"], e=CFG["e"], edge_dim=CFG["D"],
+                               first_graph=rank * distinct)
+    return S.tile_batch(base, B // distinct).to(device)
+
+
+def build_model(device):
+    import gnn_qot_estimation_amd as q
+    torch.manual_seed(0)
+    m = q.TopologicalGNN(CFG["n"], CFG["H"], CFG["out"], CFG["D"], dropout_p=CFG["dropout"],
+                         num_layers=CFG["layers"]).to(device)
+    m.train()
+    return m
+
+
+class TrainStep:
+    """zero_grad -> forward -> SmoothL1 -> backward -> all-reduce -> SGD, eager or HIP-graph."""
+
+    def __init__(self, model, batch, world, use_graph):
+        from gnn_qot_estimation_amd.dp import FlatModel
+        self.model, self.batch, self.world = model, batch, world
+        self.flat = FlatModel(model)
+        self.flat.broadcast_params()
+        self.opt = torch.optim.SGD([self.flat.leaf], lr=0.1, momentum=0.9)
+        self.y = batch.y.view(-1, CFG["out"])
+        self.loss = torch.zeros((), device=batch.y.device)
+        self.graph_fb = None
+        self.graph_opt = None
+        self.use_graph = use_graph
+
+    def _fwd_bwd(self):
+        self.batch._qot_cache = {}           # graph prep (CSR/CSC build) is part of every step
+        self.flat.zero_grad()
+        out = self.model(self.batch)
+        loss = F.smooth_l1_loss(out, self.y)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _eager(self):
+        self._fwd_bwd()
+        self.flat.all_reduce_grads()
+        self.opt.step()
+
+    def capture(self):
+        """Capture forward+backward and the optimizer update as two HIP graphs; the RCCL
+        all-reduce stays an eager call between them (one launch per step)."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self._fwd_bwd()
+        self.graph_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_opt):
+            self.opt.step()
+
+    def __call__(self):
+        if self.graph_fb is None:
+            self._eager()
+        else:
+            self.graph_fb.replay()
+            self.flat.all_reduce_grads()
+            self.graph_opt.replay()
+
+
+def event_time_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters
+
+
+def kernel_table(model, batch):
+    """Time each hand-written kernel of the step standalone (events on the launch stream) and
+    price it with the ALGORITHMIC bytes of DESIGN.md's kernel table (each distinct input
+    element read once, each output written once, int32 graph structure)."""
+    from gnn_qot_estimation_amd import _lib, functional as QF
+    from gnn_qot_estimation_amd.graph import build_graph_index, cached_i32, batch_index_for
+    P = _lib.ptr
+    dev = batch.edge_attr.device
+    N, E, H, D = batch.num_nodes, batch.num_edges, CFG["H"], CFG["D"]
+    K = 2 * D
+    g = build_graph_index(batch.edge_index, N)
+    f = lambda *s: torch.randn(*s, device=dev)
+    qkvs, gout, x = f(N, 4 * H), f(N, H), f(N, H)
+    ea = batch.edge_attr
+    we, w1, b1 = f(H, D), f(K, D), f(K)
+    out, stats = torch.empty(N, H, device=dev), torch.empty(N, 2, device=dev)
+    gq = torch.empty(N, 4 * H, device=dev)
+    escr, delta = torch.empty(E, 2, device=dev), torch.empty(N, device=dev)
+    pds, pal = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev)
+    A = torch.empty(N, (K + 2) * H, device=dev)
+    GA = f(N, K * H)
+    gw1, gb1 = torch.zeros(K, D, device=dev), torch.zeros(K, device=dev)
+    off = lambda t, k: t.data_ptr() + 4 * k
+    csr = 4 * E + 4 * (N + 1)
+    rows = []
+
+    def add(name, fn, bytes_, flops=0):
+        ms = event_time_ms(fn)
+        rows.append(dict(kernel=name, ms=ms, alg_bytes=bytes_, gbs=bytes_ / ms / 1e6, flops=flops))
+
+    _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H), 4 * H, P(ea), P(we),
+              P(g.rowptr), P(g.col), P(g.eid), P(out), P(stats), N, H, D)
+    add("tconv_fwd", lambda: _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H),
+                                       4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), P(out), P(stats), N, H, D),
+        4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
+    add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
+                                           4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), off(gq, 0),
+                                           4 * H, P(escr), P(delta), P(pds), P(pal), N, H, D),
+        4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 8 * E + 4 * N + 8 * N * D)
+    add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), off(qkvs, 0), 4 * H, P(escr), P(delta),
+                                           P(g.rowptr_t), P(g.col_t), P(g.pos_t), off(gq, H), off(gq, 2 * H), 4 * H, N, H),
+        2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)
+    add("nnconv_agg_fwd", lambda: _lib.call("qot_nnconv_agg", P(x), H, P(ea), P(w1), P(b1), P(g.rowptr), P(g.col),
+                                            P(g.eid), None, P(g.invdeg), 0, P(A), N, H, D),
+        N * H * 4 + N * (K + 2) * H * 4 + E * D * 4 + csr + 4 * E + 4 * N)
+    add("nnconv_agg_bwd", lambda: _lib.call("qot_nnconv_agg", P(gout), H, P(ea), P(w1), P(b1), P(g.rowptr_t),
+                                            P(g.col_t), P(g.pos_t), P(g.eid), P(g.invdeg), 1, P(A), N, H, D),
+        N * H * 4 + N * (K + 2) * H * 4 + E * D * 4 + csr + 8 * E + 4 * N)
+    add("nnconv_bwd_edge", lambda: _lib.call("qot_nnconv_bwd_edge", P(GA), K * H, P(x), H, P(ea), P(w1), P(b1),
+                                             P(g.rowptr), P(g.col), P(g.eid), P(g.invdeg), P(gw1), P(gb1), N, H, D),
+        N * K * H * 4 + N * H * 4 + E * D * 4 + csr + 4 * E + 4 * N)
+    add("csr_build", lambda: build_graph_index(batch.edge_index, N), 16 * E + 7 * 4 * E + 3 * 4 * N)
+    return rows
+
+
+def cpu_baseline(sample_graphs):
+    """Oracle (PyG-style sparse restatement) train step on the host cores, bounded sample."""
+    from gnn_qot_estimation_amd import synthetic as S
+    from oracle import sparse as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = O.TopologicalGNN(CFG["n"], CFG["H"], CFG["out"], CFG["D"], dropout_p=CFG["dropout"])
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    b = S.topological_batch(CFG["cfg"], sample_graphs, n=CFG["n"], e=CFG["e"], edge_dim=CFG["D"])
+    y = b.y.view(-1, CFG["out"])
+
+    def step():
+        opt.zero_grad()
+        loss = F.smooth_l1_loss(m(b), y)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 2 or (time.perf_counter() - t0 < 10.0 and iters < 20):
+        step()
+        iters += 1
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=sample_graphs / dt, unit="graphs/s", cores=cores, kind="port",
+                sample=f"{iters} train steps of {sample_graphs} graphs (n=100,e=400,H=64; PyG-style [E,H*H] NNConv) "
+                       f"after 1 warm-up, {dt:.2f} s/step, torch {torch.__version__} CPU")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from gnn_qot_estimation_amd import _lib
+    _lib.load()
+
+    batch = make_batch(rank, device)
+    model = build_model(device)
+    step = TrainStep(model, batch, world, use_graph=not args.no_graph)
+    if step.use_graph:
+        step.capture()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(step.loss.item())
+    if not (loss == loss) or loss in (float("inf"), float("-inf")):
+        raise SystemExit(f"non-finite loss {loss}")
+
+    if rank == 0:
+        graphs = CFG["B"] * world * args.steps
+        res = {
+            "metric": "graphs/sec (train step) on 100-node/400-edge synthetic topologies, batch=1024",
+            "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 2-layer TopologicalGNN (TransformerConv+NNConv) hidden=64, "
+                                   "100-node/400-directed-edge topologies, batch=1024 graphs per GPU, dropout 0.5, "
+                                   "SGD momentum 0.9, SmoothL1; CSR build included in every step",
+                       "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world,
+                       "launch": "eager" if step.graph_fb is None else "hip-graph replay (fwd+bwd, optimizer)",
+                       "parallelism": f"dp{world}", "final_loss": loss},
+        }
+        rows = kernel_table(model, batch)
+        dom = max(rows, key=lambda r: r["ms"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom["kernel"])
+        res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                           "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
+        res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+"""Data-parallel path on CPU with gloo, world_size 2: sharding by
+contiguous graph ranges + ONE flat-gradient all-reduce reproduces the single-process
+gradient.  The model here is the CPU oracle (the HIP modules have no CPU path); what is
+under test is gnn_qot_estimation_amd.dp / batch.shard_graphs, which are device-agnostic."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from gnn_qot_estimation_amd import synthetic as S
+        from gnn_qot_estimation_amd.batch import shard_graphs
+        from gnn_qot_estimation_amd.dp import FlatModel
+        from oracle import sparse as O
+        torch.manual_seed(0)
+        if kind == "topo":
+            full = S.topological_batch(2, 8, n=12, e=30)
+            model = O.TopologicalGNN(12, 8, 3, 4, dropout_p=0.0)
+        else:
+            full = S.lightpath_batch(9)          # uneven LUT counts per shard (4 vs 5 graphs)
+            model = O.LightpathGNN(5, 8, 3, 1, dropout_p=0.0).eval()    # eval: BN stats not sharded
+        if rank == 1:                            # params must come from rank 0
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        flat = FlatModel(model)
+        flat.broadcast_params()
+        shard = shard_graphs(full, rank, world)
+        flat.zero_grad()
+        if kind == "topo":
+            loss = F.smooth_l1_loss(model(shard), shard.y.view(-1, 3))
+            loss.backward()
+            flat.all_reduce_grads()
+        else:
+            out, lb = model(shard)
+            loss = F.smooth_l1_loss(out, shard.y[lb])
+            loss.backward()
+            flat.all_reduce_grads(weight=torch.tensor(float(out.shape[0])))
+        if rank == 0:
+            ret["grad"] = flat.flat_grad.clone()
+            ret["param"] = flat.flat_param.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["topo", "lightpath"])
+def test_two_rank_gradient_matches_single_process(kind):
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+        g2, p2 = ret["grad"], ret["param"]
+    from gnn_qot_estimation_amd import synthetic as S
+    from gnn_qot_estimation_amd.dp import FlatModel
+    from oracle import sparse as O
+    torch.manual_seed(0)
+    if kind == "topo":
+        full = S.topological_batch(2, 8, n=12, e=30)
+        model = O.TopologicalGNN(12, 8, 3, 4, dropout_p=0.0)
+        flat = FlatModel(model)
+        F.smooth_l1_loss(model(full), full.y.view(-1, 3)).backward()
+    else:
+        full = S.lightpath_batch(9)
+        model = O.LightpathGNN(5, 8, 3, 1, dropout_p=0.0).eval()
+        flat = FlatModel(model)
+        out, lb = model(full)
+        F.smooth_l1_loss(out, full.y[lb]).backward()
+    assert torch.allclose(p2, flat.flat_param)
+    assert torch.allclose(g2, flat.flat_grad, rtol=1e-4, atol=1e-7), (g2 - flat.flat_grad).abs().max()
+
+
+def test_flat_model_keeps_state_dict_and_single_leaf():
+    from gnn_qot_estimation_amd.dp import FlatModel
+    from oracle import sparse as O
+    m = O.TopologicalGNN(10, 8, 3, 4)
+    keys = list(m.state_dict().keys())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatModel(m)
+    assert list(m.state_dict().keys()) == keys
+    assert all(torch.equal(before[k], v) for k, v in m.state_dict().items())
+    assert flat.numel == sum(p.numel() for p in m.parameters())
+    opt = torch.optim.SGD([flat.leaf], lr=0.5)
+    flat.flat_grad.fill_(1.0)
+    opt.step()
+    assert torch.allclose(m.conv2.bias, before["conv2.bias"] - 0.5)   # views follow the fused update
