@@ -29,7 +29,7 @@ SIGNATURES = {
     "qot_abi_version": (_int, []),
     "qot_error_string": (C.c_char_p, [_int]),
     "qot_csr_workspace_bytes": (_sz, [_i64, _i64, _int]),
-    "qot_csr_build": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "qot_csr_build": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "qot_i64_to_i32": (_int, [_p, _p, _i64, _p]),
     "qot_batch_ptr": (_int, [_p, _i64, _i64, _p, _p]),
     "qot_embed_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
@@ -39,6 +39,7 @@ SIGNATURES = {
                                  _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
+    "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_bwd_edge": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
                                    _int, _p]),
     "qot_act_fwd": (_int, [_p, _p, _i64, _f, _f, _u64, _p, _p]),

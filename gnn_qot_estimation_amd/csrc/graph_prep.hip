@@ -65,13 +65,15 @@ __global__ void lower_bound_kernel(const uint32_t* __restrict__ skeys, int64_t c
 }
 
 __global__ void csc_fill_kernel(const uint32_t* __restrict__ svals2, const int32_t* __restrict__ row,
-                                int32_t* __restrict__ col_t, int32_t* __restrict__ pos_t, int64_t cap,
+                                const int32_t* __restrict__ eid, int32_t* __restrict__ col_t,
+                                int32_t* __restrict__ pos_t, int32_t* __restrict__ eid_t, int64_t cap,
                                 int64_t N) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= cap) return;
     int32_t p = (int32_t)svals2[t];
     int32_t r = row[p];
     pos_t[t] = p;
+    eid_t[t] = eid[p];
     col_t[t] = (r < N) ? r : 0;
 }
 
@@ -121,8 +123,8 @@ extern "C" size_t qot_csr_workspace_bytes(int64_t E, int64_t N, int gat_self_loo
 
 extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_loops,
                              int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
-                             int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, float* invdeg,
-                             void* workspace, size_t workspace_bytes, qot_stream_t stream_) {
+                             int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
+                             float* invdeg, void* workspace, size_t workspace_bytes, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (E < 0 || N < 0 || !rowptr || !rowptr_t || !invdeg) return QOT_ERR_BADARG;
     if (N >= (int64_t(1) << 31) - 1 || E + N >= (int64_t(1) << 31) - 1) return QOT_ERR_UNSUPPORTED;
@@ -138,7 +140,7 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
         return QOT_OK;
     }
     if (!edge_index && E > 0) return QOT_ERR_BADARG;
-    if (!col || !eid || !row || !col_t || !pos_t || !workspace) return QOT_ERR_BADARG;
+    if (!col || !eid || !row || !col_t || !pos_t || !eid_t || !workspace) return QOT_ERR_BADARG;
     unsigned bits = key_bits(N);
     size_t temp = 0;
     QOT_HIP(sort_temp_bytes(cap, bits, temp));
@@ -162,7 +164,7 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
     QOT_HIP(rocprim::radix_sort_pairs(tmp, temp, ka, kb, va, vb, (unsigned)cap, 0u, bits, stream));
     lower_bound_kernel<<<grid_for(N + 1, T), T, 0, stream>>>(kb, cap, N, rowptr_t);
     QOT_LAUNCH_CHECK();
-    csc_fill_kernel<<<grid_for(cap, T), T, 0, stream>>>(vb, row, col_t, pos_t, cap, N);
+    csc_fill_kernel<<<grid_for(cap, T), T, 0, stream>>>(vb, row, eid, col_t, pos_t, eid_t, cap, N);
     QOT_LAUNCH_CHECK();
     invdeg_kernel<<<grid_for(N, T), T, 0, stream>>>(rowptr, invdeg, N);
     QOT_LAUNCH_CHECK();

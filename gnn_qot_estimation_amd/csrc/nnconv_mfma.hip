@@ -1,0 +1,336 @@
+// NNConv fused gather -> LDS operand tile -> fp32 MFMA  (H = 64).
+//
+// out[i,:] = bias + A_i @ Wcat,  A_i = [inv_i * sum_e h_e[k] x_j (k<K) | inv_i * sum_e x_j | x_i]
+// (see nnconv.hip for the algebra; reference site topological_training/models.py:57).
+// The unfused path writes A ([N, 640] fp32 = 262 MB at B=1024) to HBM and reads it back in
+// a library GEMM; here a workgroup builds the 32 x 640 operand tile of 32 consecutive
+// destinations directly in LDS and multiplies it on the matrix cores, so HBM sees only
+// x (read), the edge features / CSR, and out (written).
+//
+//   phase 1  8 lanes per destination (2 x float4 = 64 channels), all 32 destinations at once;
+//            blocks 0..K land in LDS in fragment-grouped order (at4_slot): two conflict-free
+//            ds_write_b128 per lane per block.
+//   phase 2  4 waves = 2 column halves x 2 K halves; each wave chains
+//            v_mfma_f32_32x32x2_f32 on one 32x32 accumulator.  A fragments: ONE conflict-free
+//            ds_read_b128 per 4 MFMAs (measured: a ds_read_b32 + swizzle per MFMA capped the
+//            loop at ~105 of the ~135 TFLOP/s the register-fed loop reaches).
+//            B fragment: Wcat pre-permuted on the host side into fragment order so a lane
+//            reads 16 B = 4 consecutive k-steps, a wave 1 KiB contiguous (L2-resident, 160 KB).
+//   root     the destination's own row (block K+1) is kept in registers during phase 2 and
+//            then overwrites block 0's slots: 72 KB of LDS instead of 80 KB, which is what
+//            lets TWO workgroups share a CU (2 x 80 KB needs every byte of the 160 KiB and
+//            was measured to run one workgroup per CU: gather and MFMA phases serialised).
+//   phase 3  K halves summed through LDS, bias added, 128-B row segments stored.
+// One workgroup gathers while its CU-mate owns the MFMA pipes.  TRANSPOSE runs the adjoint (grad_x) over the CSC with the mean scale taken at
+// the gathered end.
+#include "common.hpp"
+
+namespace qot {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS operand tile, "fragment-grouped": k = 8*g + 2*r + hi  ->  float4 slot
+//   At4[(2*g + hi)*32 + (i ^ (g & 7))] component r
+// so the 4 A fragments a lane feeds to 4 consecutive MFMAs are ONE ds_read_b128, and the
+// gather's 8 channels per lane (= one group g) are TWO ds_write_b128 (hi = 0 / 1).  The XOR
+// spreads the 8 lanes of a destination (g & 7 = 0..7) over all 32 banks: both sides
+// conflict-free.
+__device__ __forceinline__ int at4_slot(int g, int hi, int i) { return (2 * g + hi) * 32 + (i ^ (g & 7)); }
+
+// Phase 1.  8 lanes per destination (2 x float4 = 64 channels each), so the 32 destinations of
+// a tile are gathered in ONE pass by the 256 threads.  Lane `sub` of a destination's group
+// prefetches the (source, edge id, edge features) of in-edge `sub` and evaluates that edge's
+// h = relu(W1 ea + b1) once; the per-edge loop then only broadcasts (8-lane shuffles) and
+// streams the 256-B source rows, four edges in flight per group.
+// Returns the destination's own row (root block) in registers; blocks 0..K go to LDS.
+template <int D, bool TRANSPOSE>
+__device__ __forceinline__ void nnconv_gather_tile(
+    float* __restrict__ At, const float* __restrict__ x, int ldx, const float* __restrict__ ea,
+    const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
+    int64_t tile0, int64_t N, float4& root0, float4& root1) {
+    constexpr int K = 2 * D;
+    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int c0 = 8 * sub;
+    const int64_t i = tile0 + il;
+    float4 acc0[K + 1], acc1[K + 1];
+#pragma unroll
+    for (int kk = 0; kk <= K; ++kk) { acc0[kk] = f4zero(); acc1[kk] = f4zero(); }
+    root0 = f4zero(); root1 = f4zero();
+    int beg = 0, end = 0;
+    if (i < N) { beg = rowptr[i]; end = rowptr[i + 1]; }
+    for (int base = beg; base < end; base += 8) {
+        // one edge per lane: indices, edge features, edge-MLP hidden vector
+        const int p = base + sub;
+        int myj = 0;
+        float myh[K], mysc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
+        if (p < end) {
+            myj = col[p];
+            const int64_t e = eidx[p];
+            float ee[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+            mysc = TRANSPOSE ? invdeg[myj] : 1.0f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                float h = b1[kk];
+#pragma unroll
+                for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
+                myh[kk] = fmaxf(h, 0.f) * mysc;
+            }
+        }
+        const int cnt = (end - base < 8) ? end - base : 8;
+        for (int u0 = 0; u0 < cnt; u0 += 4) {
+            float4 xa[4], xb[4];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int src = u0 + u;                       // lane of the group that owns this edge
+                const int64_t j = __shfl(myj, src, 8);
+                sc[u] = __shfl(mysc, src, 8);
+                const bool live = src < cnt;
+                const float* xr = x + (live ? j : 0) * ldx + c0;
+                xa[u] = ld4(xr);
+                xb[u] = ld4(xr + 4);
+                if (!live) sc[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int src = u0 + u;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) {
+                    float h = __shfl(myh[kk], src, 8);
+                    if (src >= cnt) h = 0.f;
+                    acc0[kk] = fma4(h, xa[u], acc0[kk]);
+                    acc1[kk] = fma4(h, xb[u], acc1[kk]);
+                }
+                acc0[K] = fma4(sc[u], xa[u], acc0[K]);
+                acc1[K] = fma4(sc[u], xb[u], acc1[K]);
+            }
+        }
+    }
+    if (i < N) {
+        if (!TRANSPOSE) {
+            const float s = invdeg[i];
+#pragma unroll
+            for (int kk = 0; kk <= K; ++kk) { acc0[kk] = scale4(s, acc0[kk]); acc1[kk] = scale4(s, acc1[kk]); }
+        }
+        root0 = ld4(x + i * ldx + c0);
+        root1 = ld4(x + i * ldx + c0 + 4);
+    }
+    float4* At4 = reinterpret_cast<float4*>(At);
+#pragma unroll
+    for (int kk = 0; kk <= K; ++kk) {       // channels c0+{0,2,4,6} -> hi 0 ; c0+{1,3,5,7} -> hi 1
+        const int g = kk * 8 + sub;
+        At4[at4_slot(g, 0, il)] = make_float4(acc0[kk].x, acc0[kk].z, acc1[kk].x, acc1[kk].z);
+        At4[at4_slot(g, 1, il)] = make_float4(acc0[kk].y, acc0[kk].w, acc1[kk].y, acc1[kk].w);
+    }
+}
+
+// One 4-MFMA group g: A fragments = one float4 from the LDS tile, B fragments = one float4 of Wp.
+__device__ __forceinline__ f32x16 mfma_group(const float4* __restrict__ At4, int g, int hi, int r31, float4 b,
+                                             f32x16 c) {
+    const float4 a = At4[at4_slot(g, hi, r31)];
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits vmcnt(0), i.e. it
+// drains the epilogue's global stores (measured: ~30 % of the tile time went there).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// diagnostic build only (VARIANT 3): per-phase cycle sums, one adder per wave
+__device__ unsigned long long g_stamps[8];
+#define QOT_STAMP(slot)                                                              \
+    if (VARIANT == 3) {                                                              \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[slot], _t - t_prev);        \
+        t_prev = _t;                                                                 \
+    }
+
+template <int D, bool TRANSPOSE, int VARIANT = 0>
+__global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
+    const float* __restrict__ b1, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, const float* __restrict__ Wp,
+    const float* __restrict__ bias, float* __restrict__ out, int64_t N) {
+    constexpr int K = 2 * D;
+    constexpr int KM = (K + 1) * 64;        // inner dimension held in LDS (blocks 0..K)
+    constexpr int GM = KM / 16;             // float4 B groups per wave for the main part
+    constexpr int CH = (GM % 6 == 0) ? 6 : 4;   // prefetch chunk (GM = 8D+4: divisible by 4, by 6 for D=4)
+    __shared__ __attribute__((aligned(16))) float At[KM * 32];
+    const int64_t ntiles = (N + 31) / 32;
+    // persistent: 2 workgroups per CU walk the tiles; the two CU-mates drift out of phase so
+    // one gathers while the other owns the MFMA pipes
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tile0 = tile * 32;
+    float4 root0, root1;
+    unsigned long long t_prev = 0;
+    if (VARIANT == 3) t_prev = __builtin_amdgcn_s_memtime();
+
+    if (VARIANT != 1) {
+        nnconv_gather_tile<D, TRANSPOSE>(At, x, ldx, ea, w1, b1, rowptr, col, eidx, invdeg, tile0, N, root0, root1);
+    } else {
+        for (int t = threadIdx.x; t < KM * 32; t += 256) At[t] = 1.0f + (float)(t & 7);
+        root0 = root1 = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    QOT_STAMP(0)
+    __syncthreads();
+    QOT_STAMP(1)
+    if (VARIANT == 2) {   // ablation: gather only
+        if (threadIdx.x < 32 && tile0 + threadIdx.x < N) out[(tile0 + threadIdx.x) * 64] = At[threadIdx.x * 33] + root0.x;
+        __syncthreads();
+        continue;
+    }
+
+    const float4* At4 = reinterpret_cast<const float4*>(At);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nh = wave & 1, kh = wave >> 1;
+    const int r31 = lane & 31, hi = lane >> 5;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    // Wp: [nh][group g of 4 k-steps][lane][4]; wave (nh, kh) owns main groups kh*GM.. and
+    // root groups (2*GM + kh*4)..
+    const float4* wpn = reinterpret_cast<const float4*>(Wp) + (int64_t)nh * (2 * GM + 8) * 64 + lane;
+    const float4* wp = wpn + (int64_t)kh * GM * 64;
+    float4 rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rb[u] = wpn[(2 * GM + kh * 4 + u) * 64];
+    // B fragments (L2) of chunk ch+1 are requested before the 4*CH MFMAs of chunk ch issue
+    float4 bc[CH], bn[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) bc[u] = wp[u * 64];
+#pragma unroll 1
+    for (int ch = 0; ch < GM / CH; ++ch) {
+        if (ch + 1 < GM / CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) bn[u] = wp[((ch + 1) * CH + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, bc[u], c);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) bc[u] = bn[u];
+    }
+    QOT_STAMP(2)
+    lds_barrier();                         // everyone is done with blocks 0..K
+    QOT_STAMP(3)
+    {   // root block (x_i itself) reuses block 0's slots
+        float4* At4 = reinterpret_cast<float4*>(At);
+        const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+        At4[at4_slot(sub, 0, il)] = make_float4(root0.x, root0.z, root1.x, root1.z);
+        At4[at4_slot(sub, 1, il)] = make_float4(root0.y, root0.w, root1.y, root1.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c = mfma_group(At4, kh * 4 + u, hi, r31, rb[u], c);
+    QOT_STAMP(4)
+    // K halves meet through LDS; every wave finishes 8 of the 16 accumulator registers of its
+    // (column half), so the stores are spread over all four waves
+    float* red = At + 64 * 32;             // disjoint from block 0, which other waves may still read
+    // (compile-time register indices in both branches: a runtime index into the accumulator
+    //  vector would be lowered through scratch)
+    if (kh) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[((2 + nh) * 8 + r) * 64 + lane] = c[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[(nh * 8 + r) * 64 + lane] = c[8 + r];
+    }
+    lds_barrier();
+    {
+        const int colg = nh * 32 + r31;
+        const float bz = bias ? bias[colg] : 0.f;
+        float v[8];
+        if (kh) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = c[8 + r] + red[(nh * 8 + r) * 64 + lane] + bz;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = c[r] + red[((2 + nh) * 8 + r) * 64 + lane] + bz;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int rr = kh * 8 + r;
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            const int64_t i = tile0 + row;
+            if (i < N) out[i * 64 + colg] = v[r];
+        }
+    }
+    QOT_STAMP(5)
+    lds_barrier();                         // `red` is consumed before the next tile's gather overwrites it
+    QOT_STAMP(6)
+    }
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+static int g_variant = 0;   // ablation switch for tools/ablate_nnconv.py (0 = production)
+extern "C" void qot_debug_set_variant(int v) { g_variant = v; }
+extern "C" void qot_debug_stamps(unsigned long long* host8, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(qot::g_stamps), z, sizeof(z)); }
+    else (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(qot::g_stamps), 8 * sizeof(unsigned long long));
+}
+
+// Wp layout (built by the caller, see functional.nnconv_perm_index): with GT = (K+2)*64/8 groups
+// of 4 k-steps, for column half nh, group g, lane l, r in 0..3:
+//   Wp[((nh*GT + g)*64 + l)*4 + r] = Wcat[8*g + 2*r + (l>>5)][nh*32 + (l&31)]
+// edge_ids[p] = original edge id of slot p of the index being walked (CSR: eid; CSC: eid_t).
+extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const float* w1,
+                                const float* b1, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* edge_ids, const float* invdeg, int transpose,
+                                const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                                qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (H != 64) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
+    int grid = grid_for(N, 32);
+    if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    if (g_variant && D == 4 && !transpose) {
+        if (g_variant == 3)
+            nnconv_mfma64_kernel<4, false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+        else if (g_variant == 1)
+            nnconv_mfma64_kernel<4, false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+        else
+            nnconv_mfma64_kernel<4, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
+    QOT_DISPATCH_D(D, {
+        if (transpose)
+            nnconv_mfma64_kernel<kD, true><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+        else
+            nnconv_mfma64_kernel<kD, false><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

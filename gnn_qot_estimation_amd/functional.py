@@ -120,6 +120,26 @@ def nnconv_wcat_t(w2, b2, wroot, hin, hout, k):
     ], dim=0)
 
 
+_PERM_CACHE = {}
+
+
+def nnconv_perm_index(kt: int, device) -> torch.Tensor:
+    """Gather index that lays a [KT, 64] GEMM operand out in MFMA fragment order for
+    ``qot_nnconv_fused`` (layout: csrc/nnconv_mfma.hip)."""
+    key = (kt, str(device))
+    if key not in _PERM_CACHE:
+        nh, g, l, r = torch.meshgrid(torch.arange(2), torch.arange(kt // 8), torch.arange(64), torch.arange(4),
+                                     indexing="ij")
+        k = 8 * g + 2 * r + (l >> 5)
+        n = nh * 32 + (l & 31)
+        _PERM_CACHE[key] = (k * 64 + n).reshape(-1).to(device)
+    return _PERM_CACHE[key]
+
+
+def _fused_ok(hin, hout):
+    return hin == 64 and hout == 64
+
+
 class NNConvFn(torch.autograd.Function):
     """NNConv(aggr='mean') = aggregate-then-GEMM (see ``csrc/nnconv.hip``)."""
 
@@ -135,10 +155,18 @@ class NNConvFn(torch.autograd.Function):
             raise _lib.QotError("NNConv edge MLP must be Linear(D, 2D) -> ReLU -> Linear(2D, Hin*Hout)")
         if edge_attr.shape != (graph.num_edges_in, D):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
-        A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
-        _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                  P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-        out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
+        wcat = nnconv_wcat(w2, b2, wroot, hin, hout, K)
+        if _fused_ok(hin, hout):
+            wp = wcat.reshape(-1)[nnconv_perm_index((K + 2) * hin, x.device)]
+            out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
+            _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                      P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D)
+            A = None
+        else:
+            A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
+            _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                      P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
+            out = torch.addmm(bias, A, wcat)
         ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A)
         ctx.graph = graph
         return out
@@ -153,15 +181,26 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         gbias = g.sum(0)
+        if A is None:      # fused forward did not materialise the operand: rebuild it for dW
+            A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                      P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
         gwcat = A.t() @ g                                        # [(K+2)Hin, Hout]
         gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
         gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
         gwroot = gwcat[(K + 1) * hin:].t()
         # grad_x: same aggregation over the transposed graph, then one GEMM
-        U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
-        _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                  P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
-        gx = U @ nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        wcat_t = nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        if _fused_ok(hin, hout):
+            wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
+            gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D)
+        else:
+            U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                      P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
+            gx = U @ wcat_t
         # grad of the edge MLP's first layer
         wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
         GA = g @ wk.t()                                          # [N, K*Hin]

@@ -27,6 +27,7 @@ class GraphIndex:
     rowptr_t: torch.Tensor  # [N+1] int32, out-edges of node j
     col_t: torch.Tensor    # [cap] int32 destination of each out-edge
     pos_t: torch.Tensor    # [cap] int32 CSR slot of each out-edge
+    eid_t: torch.Tensor    # [cap] int32 original edge id of each out-edge
     invdeg: torch.Tensor   # [N] fp32 1/max(in_degree,1)
     gat_self_loops: bool
 
@@ -55,7 +56,7 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
         rowptr=torch.empty(N + 1, **i32), col=torch.empty(max(cap, 1), **i32),
         eid=torch.empty(max(cap, 1), **i32), row=torch.empty(max(cap, 1), **i32),
         rowptr_t=torch.empty(N + 1, **i32), col_t=torch.empty(max(cap, 1), **i32),
-        pos_t=torch.empty(max(cap, 1), **i32),
+        pos_t=torch.empty(max(cap, 1), **i32), eid_t=torch.empty(max(cap, 1), **i32),
         invdeg=torch.empty(max(N, 1), dtype=torch.float32, device=dev),
         gat_self_loops=gat_self_loops,
     )
@@ -66,7 +67,7 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.call("qot_csr_build", _lib.ptr(ei), E, N, int(gat_self_loops), _lib.ptr(g.rowptr), _lib.ptr(g.col),
               _lib.ptr(g.eid), _lib.ptr(g.row), _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t), _lib.ptr(g.pos_t),
-              _lib.ptr(g.invdeg), _lib.ptr(ws), ws_bytes)
+              _lib.ptr(g.eid_t), _lib.ptr(g.invdeg), _lib.ptr(ws), ws_bytes)
     return g
 
 

@@ -59,7 +59,7 @@ const char* qot_error_string(int code);
  *                        (original edge id, or -1 for an inserted self loop), row[cap]
  *                        (destination of each CSR slot)
  *   CSC by source      : rowptr_t[N+1], col_t[cap] (destination of each out-edge),
- *                        pos_t[cap] (CSR slot of that edge)
+ *                        pos_t[cap] (CSR slot of that edge), eid_t[cap] (its original edge id)
  * cap = E (+ N when gat_self_loops).  Edge order inside a destination follows the
  * original edge order (stable), so results are run-to-run bitwise reproducible.
  * gat_self_loops != 0: edges with j == i are dropped and one (n,n) edge per node is
@@ -69,7 +69,7 @@ const char* qot_error_string(int code);
 size_t qot_csr_workspace_bytes(int64_t E, int64_t N, int gat_self_loops);
 int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_loops,
                   int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
-                  int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, float* invdeg,
+                  int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg,
                   void* workspace, size_t workspace_bytes, qot_stream_t stream);
 /* int64 -> int32 narrowing of node_ids / batch vectors */
 int qot_i64_to_i32(const int64_t* in, int32_t* out, int64_t n, qot_stream_t stream);
@@ -118,6 +118,18 @@ int qot_nnconv_agg(const float* x, int ld_x, const float* edge_attr, const float
                    const float* b1, const int32_t* rowptr, const int32_t* col,
                    const int32_t* eid_or_pos, const int32_t* eid_of_pos, const float* invdeg,
                    int transpose, float* A, int64_t N, int H, int D, qot_stream_t stream);
+/* Fused form of qot_nnconv_agg + GEMM (+bias) for H == 64: the [32 x (K+2)H] operand tile is
+ * built in LDS and multiplied on the matrix cores (v_mfma_f32_32x32x2_f32), A never touches
+ * HBM.  w_perm = Wcat ([(K+2)H, H]) permuted into MFMA fragment order (layout documented in
+ * csrc/nnconv_mfma.hip).  edge_ids[p] = original edge id of slot p of the index walked (eid for
+ * the CSR, eid_t for the CSC).  transpose != 0: adjoint over the CSC with w_perm built from
+ * Wcat^T blocks (grad_x).  bias may be NULL.  Returns QOT_ERR_UNSUPPORTED for H != 64 (callers then
+ * use qot_nnconv_agg + a library GEMM). */
+int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const float* w1,
+                     const float* b1, const int32_t* rowptr, const int32_t* col,
+                     const int32_t* edge_ids, const float* invdeg, int transpose,
+                     const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                     qot_stream_t stream);
 /* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
  * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
 int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,
