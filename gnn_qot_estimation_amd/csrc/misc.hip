@@ -302,7 +302,10 @@ extern "C" int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* g
     if (!grad_out || !ids || !grad_table) return QOT_ERR_BADARG;
     const size_t lds = (size_t)V * H * 4;
     if (lds <= 64 * 1024) {
-        int rpb = 2048;
+        // enough workgroups to fill the chip (>= 1024 when N allows), but each still folds
+        // >= 64 rows into its LDS table before touching global atomics
+        int64_t rpb64 = (N + 511) / 512;
+        int rpb = (int)(rpb64 < 64 ? 64 : rpb64);
         embed_bwd_kernel<true><<<grid_for(N, rpb), 256, lds, (hipStream_t)stream>>>(grad_out, ids, grad_table, N, V, H, rpb);
     } else {
         int rpb = 256;

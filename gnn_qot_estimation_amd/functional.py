@@ -7,6 +7,7 @@ hipBLASLt on the matrix cores) -- the north star reserves MFMA for exactly those
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -120,6 +121,19 @@ def nnconv_wcat_t(w2, b2, wroot, hin, hout, k):
     ], dim=0)
 
 
+def gemm_tn(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """``a.t() @ g`` for ``a [N, KT]``, ``g [N, 64]`` through ``qot_gemm_tn`` (streaming split-K
+    MFMA kernel); other shapes use the library GEMM."""
+    n, kt = a.shape
+    if g.shape[1] != 64 or kt % 128 != 0 or kt > 1280 or n == 0 or os.environ.get("QOT_DISABLE_GEMM_TN"):
+        return a.t() @ g
+    a, g = a.contiguous(), g.contiguous()
+    out = torch.empty(kt, 64, dtype=torch.float32, device=a.device)
+    ws = torch.empty(_lib.load().qot_gemm_tn_workspace_floats(kt), dtype=torch.float32, device=a.device)
+    _lib.call("qot_gemm_tn", P(a), kt, P(g), 64, n, kt, P(out), P(ws))
+    return out
+
+
 _PERM_CACHE = {}
 
 
@@ -185,7 +199,7 @@ class NNConvFn(torch.autograd.Function):
             A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-        gwcat = A.t() @ g                                        # [(K+2)Hin, Hout]
+        gwcat = gemm_tn(A, g)                                    # [(K+2)Hin, Hout] = A^T g
         gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
         gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
         gwroot = gwcat[(K + 1) * hin:].t()

@@ -130,6 +130,13 @@ int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const flo
                      const int32_t* edge_ids, const float* invdeg, int transpose,
                      const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
                      qot_stream_t stream);
+/* C[KT,64] = A[N,KT]^T @ G[N,64] (fp32 MFMA, operands streamed from HBM in fragment order,
+ * deterministic slab reduction).  Weight-gradient GEMM of NNConv (gWcat = A^T g) -- the shape
+ * library GEMMs run at 13-28 TFLOP/s.  KT multiple of 128, <= 1280.  workspace:
+ * qot_gemm_tn_workspace_floats(KT) floats. */
+size_t qot_gemm_tn_workspace_floats(int KT);
+int qot_gemm_tn(const float* A, int lda, const float* G, int ldg, int64_t N, int KT, float* C,
+                float* workspace, qot_stream_t stream);
 /* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
  * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
 int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,

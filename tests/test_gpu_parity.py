@@ -158,3 +158,54 @@ def test_dropout_statistics_and_replay(cuda_device):
     assert torch.equal(g != 0, m)
     y2 = QF.ActFn.apply(x, 0.01, 0.5, 1234, torch.tensor(8, device=cuda_device))
     assert not torch.equal(y2 != 0, m)
+
+
+@pytest.mark.parametrize("n,kt", [(1000, 640), (37, 128), (102400, 640), (8, 1280)])
+def test_gemm_tn_matches_fp64(cuda_device, n, kt):
+    """qot_gemm_tn (streaming split-K MFMA, deterministic slab reduce) vs an fp64 product."""
+    from gnn_qot_estimation_amd.functional import gemm_tn
+    torch.manual_seed(0)
+    a = torch.randn(n, kt, device=cuda_device)
+    g = torch.randn(n, 64, device=cuda_device)
+    out = gemm_tn(a, g)
+    ref = a.double().t() @ g.double()
+    assert rel_err(out, ref) <= 1e-5
+    assert torch.equal(out, gemm_tn(a, g))          # bitwise reproducible (no atomics)
+
+
+@pytest.mark.parametrize("gat", [False, True])
+def test_csr_build_matches_stable_cpu_sort(cuda_device, gat):
+    """Graph prep: CSR-by-destination keeps the caller's edge order inside a destination;
+    GAT mode drops j==i edges and appends one self loop per node (last in its row)."""
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    torch.manual_seed(0)
+    n, e = 500, 4000
+    ei = torch.randint(0, n, (2, e))
+    ei[:, :50] = ei[0, :50]                     # some self loops
+    g = build_graph_index(ei.to(cuda_device), n, gat_self_loops=gat)
+    src, dst = ei[0], ei[1]
+    ids = torch.arange(e)
+    if gat:
+        keep = src != dst
+        src, dst, ids = src[keep], dst[keep], ids[keep]
+        loops = torch.arange(n)
+        src, dst, ids = torch.cat([src, loops]), torch.cat([dst, loops]), torch.cat([ids, torch.full((n,), -1)])
+    order = torch.sort(dst, stable=True).indices
+    rowptr = torch.zeros(n + 1, dtype=torch.long)
+    rowptr[1:] = torch.bincount(dst, minlength=n).cumsum(0)
+    m = src.numel()
+    assert torch.equal(g.rowptr.cpu().long(), rowptr)
+    assert torch.equal(g.col.cpu().long()[:m], src[order])
+    assert torch.equal(g.eid.cpu().long()[:m], ids[order])
+    assert torch.equal(g.row.cpu().long()[:m], dst[order])
+    # CSC: out-edges of j in CSR-slot order
+    csr_src = src[order]
+    order_t = torch.sort(csr_src, stable=True).indices
+    rowptr_t = torch.zeros(n + 1, dtype=torch.long)
+    rowptr_t[1:] = torch.bincount(csr_src, minlength=n).cumsum(0)
+    assert torch.equal(g.rowptr_t.cpu().long(), rowptr_t)
+    assert torch.equal(g.pos_t.cpu().long()[:m], order_t)
+    assert torch.equal(g.col_t.cpu().long()[:m], dst[order][order_t])
+    assert torch.equal(g.eid_t.cpu().long()[:m], ids[order][order_t])
+    deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
+    assert torch.allclose(g.invdeg.cpu(), 1.0 / deg)
