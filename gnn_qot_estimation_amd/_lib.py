@@ -38,10 +38,15 @@ SIGNATURES = {
     "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
                                  _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
+    "qot_tconv_wedge_workspace_floats": (_sz, [_int, _int]),
+    "qot_tconv_wedge_grad": (_int, [_p, _int, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_gemm_tn_workspace_floats": (_sz, [_int]),
     "qot_gemm_tn": (_int, [_p, _int, _p, _int, _i64, _int, _p, _p, _p]),
+    "qot_nnconv_gradh_workspace_floats": (_sz, [_int]),
+    "qot_nnconv_gradh_fused": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
+                                      _int, _p]),
     "qot_nnconv_bwd_edge": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
                                    _int, _p]),
     "qot_act_fwd": (_int, [_p, _p, _i64, _f, _f, _u64, _p, _p]),

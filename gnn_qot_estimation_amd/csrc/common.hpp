@@ -61,6 +61,18 @@ __device__ __forceinline__ uint32_t rng32(uint64_t seed, uint64_t step, uint64_t
     return (uint32_t)(z >> 32);
 }
 
+// out[t] = sum_b partials[b*n + t]: one wave per output element, lanes stride over the blocks
+// (coalescing does not matter here -- latency does: a serial loop over 512 partials costs ~120 us).
+// Fixed order: lane-strided partial sums, then a fixed shuffle tree -> bitwise reproducible.
+__device__ __forceinline__ float wave_sum_partials(const float* __restrict__ partials, int nblk, int n, int t) {
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int b = lane; b < nblk; b += 64) s += partials[(int64_t)b * n + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
 inline int grid_for(int64_t work, int per_block) { return (int)((work + per_block - 1) / per_block); }
 
 }  // namespace qot

@@ -273,6 +273,198 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// grad of the edge MLP's first layer (nn.0.weight / nn.0.bias), fused.
+//   dL/dh_e[k] = invdeg_i * < GA_i[k,:], x_j > ,  GA_i[k,a] = sum_o g_i[o] * W2[a*64+o, k]
+// The unfused path materialises GA ([N, 512] fp32, a 6.7 GFLOP library GEMM measured at 291 us)
+// and re-reads it per destination.  Here, per tile of 32 destinations:
+//   1. g rows -> LDS in MFMA fragment order (8 KB)
+//   2. GA tile [32 x 512] = g_tile @ Bm on the matrix cores (4 waves x 4 column blocks,
+//      128 v_mfma_f32_32x32x2_f32 per wave), accumulators -> LDS row-major (66 KB, padded rows)
+//   3. 8 lanes per destination: GA_i[:, 8 channels] in registers (64 VGPRs), in-edges streamed
+//      as in the forward gather; 8 partial dots per edge, transpose-reduced over the 8 lanes
+//      (7 shuffles) so lane s ends with k = s; relu mask recomputed from the edge features.
+// Per-lane accumulators of (gw1[k,:], gb1[k]) live across the persistent loop; block partials
+// are summed in a fixed order afterwards (bitwise reproducible, no float atomics).
+constexpr int kGaLd = 516;    // padded GA row (floats): rows 4 banks apart
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
+    const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, const float* __restrict__ ea,
+    const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
+    const float* __restrict__ Bp, float* __restrict__ partials, int64_t N) {
+    constexpr int K = 2 * D;
+    static_assert(K <= 8 || K == 16 || K == 10 || K == 12 || K == 14, "K");
+    constexpr int NB = K * 2;               // 32-column blocks of GA (K*64/32)
+    constexpr int NBW = NB / 4;             // per wave
+    __shared__ __attribute__((aligned(16))) float Gt[8 * 2 * 32 * 4];     // g tile, fragment-grouped
+    __shared__ __attribute__((aligned(16))) float GAt[32 * (K * 64 + 4)];  // GA tile, row-major padded
+    constexpr int LDGA = K * 64 + 4;
+    float4* Gt4 = reinterpret_cast<float4*>(Gt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int c0 = 8 * sub;
+    const int64_t ntiles = (N + 31) / 32;
+
+    // lane-owned slice of the first edge-MLP layer: row k = sub (and sub + 8 when K > 8)
+    constexpr int KPL = (K + 7) / 8;        // k rows per lane
+    float wrow[KPL][D], brow[KPL], aw[KPL][D], ab[KPL];
+#pragma unroll
+    for (int q = 0; q < KPL; ++q) {
+        const int k = sub + 8 * q;
+        brow[q] = (k < K) ? b1[k] : 0.f;
+        ab[q] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { wrow[q][d] = (k < K) ? w1[k * D + d] : 0.f; aw[q][d] = 0.f; }
+    }
+
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tile0 = tile * 32;
+        const int64_t i = tile0 + il;
+        // 1. g tile -> LDS (fragment-grouped, group index = sub)
+        {
+            float4 g0 = f4zero(), g1 = f4zero();
+            if (i < N) { g0 = ld4(g + i * ldg + c0); g1 = ld4(g + i * ldg + c0 + 4); }
+            Gt4[at4_slot(sub, 0, il)] = make_float4(g0.x, g0.z, g1.x, g1.z);
+            Gt4[at4_slot(sub, 1, il)] = make_float4(g0.y, g0.w, g1.y, g1.w);
+        }
+        lds_barrier();
+        // 2. GA tile on the matrix cores
+        {
+            float4 af[8];
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) af[gq] = Gt4[at4_slot(gq, hi, r31)];
+#pragma unroll
+            for (int t = 0; t < NBW; ++t) {
+                const int nb = wave * NBW + t;
+                const float4* bp = reinterpret_cast<const float4*>(Bp) + (int64_t)nb * 8 * 64 + lane;
+                float4 bf[8];
+#pragma unroll
+                for (int gq = 0; gq < 8; ++gq) bf[gq] = bp[gq * 64];
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < 8; ++gq) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].x, bf[gq].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].y, bf[gq].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].z, bf[gq].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].w, bf[gq].w, c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    GAt[row * LDGA + nb * 32 + r31] = c[r];
+                }
+            }
+        }
+        lds_barrier();
+        // 3. per-edge dots
+        if (i < N) {
+            float ga[K][8];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float4 u0 = *reinterpret_cast<const float4*>(&GAt[il * LDGA + k * 64 + c0]);
+                const float4 u1 = *reinterpret_cast<const float4*>(&GAt[il * LDGA + k * 64 + c0 + 4]);
+                ga[k][0] = u0.x; ga[k][1] = u0.y; ga[k][2] = u0.z; ga[k][3] = u0.w;
+                ga[k][4] = u1.x; ga[k][5] = u1.y; ga[k][6] = u1.z; ga[k][7] = u1.w;
+            }
+            const float sc = invdeg[i];
+            const int beg = rowptr[i], end = rowptr[i + 1];
+            for (int base = beg; base < end; base += 8) {
+                const int p = base + sub;
+                int myj = 0;
+                float mye[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) mye[d] = 0.f;
+                if (p < end) {
+                    myj = col[p];
+                    const int64_t e = eidx[p];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+                }
+                const int cnt = (end - base < 8) ? end - base : 8;
+                for (int u = 0; u < cnt; ++u) {
+                    const int64_t j = __shfl(myj, u, 8);
+                    float ee[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u, 8);
+                    const float4 x0 = ld4(x + j * ldx + c0), x1 = ld4(x + j * ldx + c0 + 4);
+                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int q = 0; q < KPL; ++q) {
+                        float pd[8];
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const int k = 8 * q + kk;
+                            float a = 0.f;
+                            if (k < K) {
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) a = fmaf(ga[k < K ? k : 0][t], xv[t], a);
+                            }
+                            pd[kk] = a;
+                        }
+                        // transpose-reduce 8 values over 8 lanes: lane s ends with the total of value s
+                        float t4[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const float keep = (sub & 4) ? pd[m + 4] : pd[m];
+                            const float send = (sub & 4) ? pd[m] : pd[m + 4];
+                            t4[m] = keep + __shfl_xor(send, 4);
+                        }
+                        float t2[2];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const float keep = (sub & 2) ? t4[m + 2] : t4[m];
+                            const float send = (sub & 2) ? t4[m] : t4[m + 2];
+                            t2[m] = keep + __shfl_xor(send, 2);
+                        }
+                        const float keep = (sub & 1) ? t2[1] : t2[0];
+                        const float send = (sub & 1) ? t2[0] : t2[1];
+                        const float tot = keep + __shfl_xor(send, 1);     // k = 8*q + sub
+                        float pre = brow[q];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);
+                        const float gh = (pre > 0.f && 8 * q + sub < K) ? tot * sc : 0.f;
+                        ab[q] += gh;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) aw[q][d] = fmaf(gh, ee[d], aw[q][d]);
+                    }
+                }
+            }
+        }
+        lds_barrier();        // GAt / Gt are rewritten by the next tile
+    }
+    // block partial: sum the 32 lane groups (fixed order) -> partials[blk][K*(D+1)]
+    float* red = GAt;
+#pragma unroll
+    for (int q = 0; q < KPL; ++q) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) red[((q * (D + 1) + d) * 32 + il) * 8 + sub] = aw[q][d];
+        red[((q * (D + 1) + D) * 32 + il) * 8 + sub] = ab[q];
+    }
+    lds_barrier();
+    if (threadIdx.x < KPL * (D + 1) * 8) {
+        const int s8 = threadIdx.x & 7, slot = threadIdx.x >> 3;       // slot = q*(D+1) + d
+        float sum = 0.f;
+        for (int g32 = 0; g32 < 32; ++g32) sum += red[(slot * 32 + g32) * 8 + s8];
+        const int q = slot / (D + 1), d = slot % (D + 1);
+        const int k = 8 * q + s8;
+        if (k < K) partials[(int64_t)blockIdx.x * (K * (D + 1)) + (d < D ? k * D + d : K * D + k)] = sum;
+    }
+}
+
+__global__ void gradh_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, int KD,
+                                         float* __restrict__ gw1, float* __restrict__ gb1) {
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per output
+    if (t >= n) return;
+    const float s = wave_sum_partials(partials, nblk, n, t);
+    if ((threadIdx.x & 63) == 0) { if (t < KD) gw1[t] = s; else gb1[t - KD] = s; }
+}
+
 }  // namespace qot
 
 using namespace qot;
@@ -331,6 +523,38 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
             nnconv_mfma64_kernel<kD, false><<<grid, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
     });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// Bp layout: for 32-column block nb of GA (column n = k*64 + a), group gq of 4 k-steps over o,
+// lane l, r:  Bp[((nb*8 + gq)*64 + l)*4 + r] = W2[a*64 + o, k]  with o = 8*gq + 2*r + (l>>5),
+// n = nb*32 + (l&31)  (built by functional.nnconv_gradh_perm_index).
+extern "C" size_t qot_nnconv_gradh_workspace_floats(int D) {
+    return (size_t)2 * 256 * 2 * (size_t)(2 * D * (D + 1));
+}
+
+extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const float* x, int ld_x,
+                                      const float* edge_attr, const float* w1, const float* b1,
+                                      const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                                      const float* invdeg, const float* b_perm, float* gw1, float* gb1,
+                                      float* workspace, int64_t N, int H, int D, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (H != 64 || D > 4) return QOT_ERR_UNSUPPORTED;      // K*64 floats of GA per row must fit LDS twice per CU
+    if (!grad_out || !x || !w1 || !b1 || !invdeg || !b_perm || !gw1 || !gb1 || !workspace || (ld_g & 3) || (ld_x & 3))
+        return QOT_ERR_BADARG;
+    int grid = grid_for(N > 0 ? N : 1, 32);
+    if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    const int K = 2 * D;
+    QOT_DISPATCH_D(D, {
+        if (kD <= 4)
+            nnconv_gradh64_kernel<(kD <= 4 ? kD : 4)><<<grid, 256, 0, stream>>>(
+                grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col, eid, invdeg, b_perm, workspace, N);
+    });
+    QOT_LAUNCH_CHECK();
+    const int n = K * (D + 1);
+    gradh_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, grid, n, K * D, gw1, gb1);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

@@ -52,6 +52,26 @@ class EmbedFn(torch.autograd.Function):
         return gt, None
 
 
+# ------------------------------------------------------------------ node-level Linear
+class LinearFn(torch.autograd.Function):
+    """``x @ W^T + b`` over the node matrix.  Forward / grad_x are library GEMMs (MFMA); the
+    weight gradient ``g^T x`` ([out, N] x [N, in], K = N ~ 1e5) goes through ``qot_gemm_tn`` when
+    ``in == 64`` -- the library runs that shape at ~12 TFLOP/s."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gemm_tn(g, x)                  # [out, in] = g^T x
+        return gx, gw, g.sum(0)
+
+
 # ------------------------------------------------------------------ TransformerConv (a2)
 class TConvFn(torch.autograd.Function):
     """Fused edge-softmax-aggregate of TransformerConv on packed projections.
@@ -97,8 +117,9 @@ class TConvFn(torch.autograd.Function):
         _lib.call("qot_tconv_bwd_src", P(g), _off(qkvs, 0), H4, P(escr), P(delta), P(graph.rowptr_t),
                   P(graph.col_t), P(graph.pos_t), _off(gqkvs, H), _off(gqkvs, 2 * H), H4, N, H)
         gqkvs[:, 3 * H:] = g
-        q = qkvs[:, :H]
-        gwe = torch.addmm(g.t() @ pal, q.t(), pds, alpha=1.0 / math.sqrt(H))
+        gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_tconv_wedge_workspace_floats(H, D), dtype=torch.float32, device=dev)
+        _lib.call("qot_tconv_wedge_grad", _off(qkvs, 0), H4, P(g), P(pds), P(pal), P(gwe), P(ws), N, H, D)
         return gqkvs, None, gwe, None
 
 
@@ -147,6 +168,19 @@ def nnconv_perm_index(kt: int, device) -> torch.Tensor:
         k = 8 * g + 2 * r + (l >> 5)
         n = nh * 32 + (l & 31)
         _PERM_CACHE[key] = (k * 64 + n).reshape(-1).to(device)
+    return _PERM_CACHE[key]
+
+
+def nnconv_gradh_perm_index(k: int, device) -> torch.Tensor:
+    """Index into wk = Wcat[:K*64] ([K*64, 64], wk[n, o]) that lays Wk^T out in fragment order
+    for ``qot_nnconv_gradh_fused``."""
+    key = ("gradh", k, str(device))
+    if key not in _PERM_CACHE:
+        nb, gq, l, r = torch.meshgrid(torch.arange(2 * k), torch.arange(8), torch.arange(64), torch.arange(4),
+                                      indexing="ij")
+        o = 8 * gq + 2 * r + (l >> 5)
+        n = nb * 32 + (l & 31)
+        _PERM_CACHE[key] = (n * 64 + o).reshape(-1).to(device)
     return _PERM_CACHE[key]
 
 
@@ -217,13 +251,21 @@ class NNConvFn(torch.autograd.Function):
             gx = U @ wcat_t
         # grad of the edge MLP's first layer
         wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
-        GA = g @ wk.t()                                          # [N, K*Hin]
-        gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
-        gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
         if hin != hout:
             raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
-        _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
-                  P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
+        if _fused_ok(hin, hout) and D <= 4:
+            bp = wk.reshape(-1)[nnconv_gradh_perm_index(K, dev)]
+            gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
+            gb1 = torch.empty(K, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_gradh_fused", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr),
+                      P(graph.col), P(graph.eid), P(graph.invdeg), P(bp), P(gw1), P(gb1), P(ws), N, hin, D)
+        else:
+            GA = g @ wk.t()                                      # [N, K*Hin]
+            gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
+            gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
+                      P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
         return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None
 
 

@@ -57,7 +57,7 @@ class TransformerConv(nn.Module):
         if graph is None:
             graph = build_graph_index(edge_index, x.shape[0])
         w, b = self.packed_weight()
-        qkvs = F.linear(x, w, b)                      # one MFMA GEMM for q|k|v|skip
+        qkvs = QF.LinearFn.apply(x, w, b)             # one MFMA GEMM for q|k|v|skip
         return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph)
 
 

@@ -106,6 +106,13 @@ int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float
                       const int32_t* pos_t, float* grad_k, float* grad_v, int ld_g, int64_t N, int H,
                       qot_stream_t stream);
 
+/* grad of lin_edge.weight: gWe[H,D] = (q/sqrt(H))^T pds + grad_out^T pal  (deterministic two-stage
+ * column reduction; workspace: qot_tconv_wedge_workspace_floats(H, D) floats). */
+size_t qot_tconv_wedge_workspace_floats(int H, int D);
+int qot_tconv_wedge_grad(const float* q, int ld, const float* grad_out, const float* pds,
+                         const float* pal, float* grad_w_edge, float* workspace, int64_t N, int H, int D,
+                         qot_stream_t stream);
+
 /* ---- NNConv (aggr = mean), factorised ----------------------------------------------
  * h_e = relu(W1 ea_e + b1) in R^K, K = 2D.  Builds the GEMM operand
  *   A[i] = [ invdeg_i * sum_e h_e[0] x_j | ... | invdeg_i * sum_e h_e[K-1] x_j |
@@ -137,6 +144,15 @@ int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const flo
 size_t qot_gemm_tn_workspace_floats(int KT);
 int qot_gemm_tn(const float* A, int lda, const float* G, int ldg, int64_t N, int KT, float* C,
                 float* workspace, qot_stream_t stream);
+/* Fused form of {GA = g @ Wk^T ; qot_nnconv_bwd_edge} for H == 64, D <= 4: the GA tile is produced
+ * by MFMA into LDS and consumed there.  b_perm: Wk^T in fragment order (csrc/nnconv_mfma.hip).
+ * workspace: qot_nnconv_gradh_workspace_floats(D) floats.  gw1/gb1 are overwritten. */
+size_t qot_nnconv_gradh_workspace_floats(int D);
+int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const float* x, int ld_x,
+                           const float* edge_attr, const float* w1, const float* b1,
+                           const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                           const float* invdeg, const float* b_perm, float* gw1, float* gb1,
+                           float* workspace, int64_t N, int H, int D, qot_stream_t stream);
 /* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
  * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
 int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,
