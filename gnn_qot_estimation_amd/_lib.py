@@ -61,6 +61,9 @@ SIGNATURES = {
     "qot_bn_apply": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p]),
     "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p]),
+    "qot_sgd_momentum": (_int, [_p, _p, _p, _i64, _f, _f, _p, _p]),
+    "qot_colsum_workspace_floats": (_sz, [_int]),
+    "qot_colsum": (_int, [_p, _int, _i64, _int, _p, _p, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),
 }

@@ -269,9 +269,82 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     st4(gx + 4 * t, o);
 }
 
+// ----------------------------------------------------------------------------- optimizer / reductions
+// SGD with momentum over the flat parameter buffer (torch.optim.SGD semantics, dampening 0, no
+// nesterov / weight decay -- topological_training/train.py:66): buf = mu*buf + g ; p -= lr*buf.
+// first_step: buf = g (torch initialises the momentum buffer with the first gradient).
+__global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                    int64_t n, float lr, float mu, const int64_t* __restrict__ step) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool first = step[0] == 0;
+    const float b = first ? g[t] : fmaf(mu, buf[t], g[t]);
+    buf[t] = b;
+    p[t] = fmaf(-lr, b, p[t]);
+}
+__global__ void bump_step_kernel(int64_t* step) { step[0] += 1; }
+
+// column sums of a row-major [N, C] matrix (bias gradients): per-block slices -> partials -> wave sums
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, int64_t N, int C,
+                                                             float* __restrict__ partials) {
+    __shared__ float4 red[256];
+    const int C4 = C / 4;
+    const int RPB = 256 / C4;
+    const int sub = threadIdx.x % C4, slot = threadIdx.x / C4;
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per;
+    const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+    float4 acc = f4zero();
+    if (slot < RPB)
+        for (int64_t r = r0 + slot; r < r1; r += RPB) acc = add4(acc, ld4(x + r * ld + 4 * sub));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 s = red[threadIdx.x];
+        for (int k = 1; k < RPB; ++k) s = add4(s, red[k * C4 + threadIdx.x]);
+        st4(partials + (int64_t)blockIdx.x * C + 4 * threadIdx.x, s);
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= C) return;
+    const float s = wave_sum_partials(partials, nblk, C, t);
+    if ((threadIdx.x & 63) == 0) out[t] = s;
+}
+constexpr int kColsumBlocks = 1024;
+
 }  // namespace qot
 
 using namespace qot;
+
+extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                                float momentum, int64_t* step_counter, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || !step_counter || (n > 0 && (!param || !grad || !momentum_buf))) return QOT_ERR_BADARG;
+    if (n > 0) {
+        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, lr, momentum, step_counter);
+        QOT_LAUNCH_CHECK();
+    }
+    bump_step_kernel<<<1, 1, 0, stream>>>(step_counter);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" size_t qot_colsum_workspace_floats(int C) { return (size_t)kColsumBlocks * (size_t)(C > 0 ? C : 0); }
+
+extern "C" int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace,
+                          qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || !x || !out || !workspace || (ld & 3)) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
+    int blocks = kColsumBlocks;
+    if (N < (int64_t)blocks * 4) blocks = (int)((N + 3) / 4);
+    colsum_partial_kernel<<<blocks, 256, 0, stream>>>(x, ld, N, C, workspace);
+    QOT_LAUNCH_CHECK();
+    colsum_final_kernel<<<grid_for(C, 4), 256, 0, stream>>>(workspace, blocks, C, out);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
 
 static const char* kErrNames[] = {"ok", "unsupported width / edge_dim (no CPU fallback)", "bad argument"};
 

@@ -46,6 +46,17 @@ class FlatModel:
     def zero_grad(self):
         self.flat_grad.zero_()
 
+    def detach_grads(self):
+        """Drop the ``.grad`` views so autograd ASSIGNS fresh gradient tensors instead of launching
+        one accumulate-add kernel per parameter; ``gather_grads`` then packs them with one kernel."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Pack the per-parameter gradients into the flat buffer (one ``cat`` kernel)."""
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.flat_grad)
+
     def rebind_grads(self):
         """Autograd may replace ``p.grad`` (e.g. after ``zero_grad(set_to_none=True)``);
         re-attach the views so accumulation lands in the flat buffer again."""
@@ -75,6 +86,24 @@ class FlatModel:
     def broadcast_params(self, src: int = 0, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat_param, src=src, group=group)
+
+
+class FusedSGD:
+    """SGD(lr, momentum) over a ``FlatModel``: ONE kernel updates every parameter
+    (``qot_sgd_momentum``; same arithmetic as ``torch.optim.SGD`` without dampening / nesterov /
+    weight decay, the reference's optimizer at ``topological_training/train.py:66``)."""
+
+    def __init__(self, flat: "FlatModel", lr: float, momentum: float = 0.0):
+        self.flat, self.lr, self.momentum = flat, float(lr), float(momentum)
+        self.buf = torch.zeros_like(flat.flat_param)
+        self.step_count = torch.zeros((), dtype=torch.long, device=flat.flat_param.device)
+
+    def step(self):
+        from . import _lib
+        if not self.flat.flat_param.is_cuda:
+            raise _lib.QotError("FusedSGD runs on the GPU only (use torch.optim.SGD on CPU)")
+        _lib.call("qot_sgd_momentum", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
+                  _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, _lib.ptr(self.step_count))
 
 
 def graph_range(num_graphs: int, rank: int, world: int):

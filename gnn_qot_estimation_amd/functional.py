@@ -52,6 +52,18 @@ class EmbedFn(torch.autograd.Function):
         return gt, None
 
 
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """``x.sum(0)`` for a contiguous fp32 ``[N, C]`` CUDA matrix (bias gradients)."""
+    n, c = x.shape
+    if n == 0 or c % 4 or c > 1024:
+        return x.sum(0)
+    x = x.contiguous()
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.load().qot_colsum_workspace_floats(c), dtype=torch.float32, device=x.device)
+    _lib.call("qot_colsum", P(x), c, n, c, P(out), P(ws))
+    return out
+
+
 # ------------------------------------------------------------------ node-level Linear
 class LinearFn(torch.autograd.Function):
     """``x @ W^T + b`` over the node matrix.  Forward / grad_x are library GEMMs (MFMA); the
@@ -69,7 +81,7 @@ class LinearFn(torch.autograd.Function):
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
         gw = gemm_tn(g, x)                  # [out, in] = g^T x
-        return gx, gw, g.sum(0)
+        return gx, gw, colsum(g)
 
 
 # ------------------------------------------------------------------ TransformerConv (a2)
@@ -228,7 +240,7 @@ class NNConvFn(torch.autograd.Function):
         hout = wroot.shape[0]
         K, D = w1.shape
         dev = x.device
-        gbias = g.sum(0)
+        gbias = colsum(g)
         if A is None:      # fused forward did not materialise the operand: rebuild it for dW
             A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
@@ -353,7 +365,7 @@ class GatFn(torch.autograd.Function):
                   P(gad), P(escr), P(delta), N, heads, C, ns)
         _lib.call("qot_gat_bwd_src", P(g), P(a_src), P(a_dst), P(escr), P(delta), P(graph.rowptr_t),
                   P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns)
-        return gz, gas, gad, g.sum(0), None, None
+        return gz, gas, gad, colsum(g), None, None
 
 
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)

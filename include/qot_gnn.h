@@ -215,6 +215,15 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
                      float* grad_x, int64_t N, int C, int relu, int batch_stats,
                      qot_stream_t stream);
 
+/* ---- train-step envelope helpers (topological_training/train.py:109-116) ----------------
+ * qot_sgd_momentum: torch.optim.SGD(lr, momentum) update over one flat buffer; step_counter is a
+ * DEVICE int64 (0 on the first step: buf = grad), bumped by the call -- graph-replay safe.
+ * qot_colsum: out[C] = column sums of x[N, C] (bias gradients), deterministic two-stage. */
+int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                     float momentum, int64_t* step_counter, qot_stream_t stream);
+size_t qot_colsum_workspace_floats(int C);
+int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace, qot_stream_t stream);
+
 /* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
 int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,
                     qot_stream_t stream);

@@ -209,3 +209,28 @@ def test_csr_build_matches_stable_cpu_sort(cuda_device, gat):
     assert torch.equal(g.eid_t.cpu().long()[:m], ids[order][order_t])
     deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
     assert torch.allclose(g.invdeg.cpu(), 1.0 / deg)
+
+
+def test_fused_sgd_matches_torch_sgd(cuda_device):
+    """FusedSGD (one kernel over the flat buffer) == torch.optim.SGD(lr, momentum) for 3 steps."""
+    from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4)).to(cuda_device)
+    b = copy.deepcopy(a)
+    flat = FlatModel(a)
+    fused = FusedSGD(flat, lr=0.1, momentum=0.9)
+    ref = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9)
+    for step in range(3):
+        x = torch.randn(32, 8, device=cuda_device)
+        flat.detach_grads(); ref.zero_grad()
+        a(x).square().mean().backward(); b(x).square().mean().backward()
+        flat.gather_grads()
+        fused.step(); ref.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+
+
+def test_colsum(cuda_device):
+    from gnn_qot_estimation_amd.functional import colsum
+    x = torch.randn(10007, 256, device=cuda_device)
+    assert rel_err(colsum(x), x.double().sum(0)) <= 1e-5
