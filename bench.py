@@ -137,36 +137,55 @@ def event_time_ms(fn, iters=20, warm=3):
 
 def kernel_table(model, batch):
     """Time each hand-written kernel of the step standalone (events on the launch stream) and
-    price it with the ALGORITHMIC bytes of DESIGN.md's kernel table (each distinct input
-    element read once, each output written once, int32 graph structure)."""
-    from gnn_qot_estimation_amd import _lib, functional as QF
-    from gnn_qot_estimation_amd.graph import build_graph_index, cached_i32, batch_index_for
+    price it with the ALGORITHMIC bytes / flops of DESIGN.md's kernel table (each distinct input
+    element read once, each output written once, int32 graph structure; 2*M*N*K per GEMM)."""
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd.functional import nnconv_perm_index, nnconv_gradh_perm_index, gemm_tn
+    from gnn_qot_estimation_amd.graph import build_graph_index
     P = _lib.ptr
+    lib = _lib.load()
     dev = batch.edge_attr.device
     N, E, H, D = batch.num_nodes, batch.num_edges, CFG["H"], CFG["D"]
     K = 2 * D
+    KT = (K + 2) * H
     g = build_graph_index(batch.edge_index, N)
     f = lambda *s: torch.randn(*s, device=dev)
     qkvs, gout, x = f(N, 4 * H), f(N, H), f(N, H)
     ea = batch.edge_attr
-    we, w1, b1 = f(H, D), f(K, D), f(K)
+    we, w1, b1, bias = f(H, D), f(K, D), f(K), f(H)
     out, stats = torch.empty(N, H, device=dev), torch.empty(N, 2, device=dev)
     gq = torch.empty(N, 4 * H, device=dev)
     escr, delta = torch.empty(E, 2, device=dev), torch.empty(N, device=dev)
     pds, pal = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev)
-    A = torch.empty(N, (K + 2) * H, device=dev)
-    GA = f(N, K * H)
+    A = torch.empty(N, KT, device=dev)
+    wp = f(KT * H)[nnconv_perm_index(KT, dev)].contiguous()
+    bp = f(K * H * H)[nnconv_gradh_perm_index(K, dev)].contiguous()
     gw1, gb1 = torch.zeros(K, D, device=dev), torch.zeros(K, device=dev)
+    ws_h = torch.empty(lib.qot_nnconv_gradh_workspace_floats(D), device=dev)
     off = lambda t, k: t.data_ptr() + 4 * k
     csr = 4 * E + 4 * (N + 1)
     rows = []
 
-    def add(name, fn, bytes_, flops=0):
+    def add(name, fn, bytes_, flops=0, bound="hbm"):
         ms = event_time_ms(fn)
-        rows.append(dict(kernel=name, ms=ms, alg_bytes=bytes_, gbs=bytes_ / ms / 1e6, flops=flops))
+        rows.append(dict(kernel=name, ms=ms, bound=bound, alg_bytes=bytes_, gbs=bytes_ / ms / 1e6, flops=flops,
+                         tflops=flops / ms / 1e9))
 
-    _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H), 4 * H, P(ea), P(we),
-              P(g.rowptr), P(g.col), P(g.eid), P(out), P(stats), N, H, D)
+    conv_in = N * H * 4 + E * D * 4 + csr + 4 * E + 4 * N        # x rows, edge features, CSR, eid, invdeg
+    add("nnconv_fused_fwd", lambda: _lib.call("qot_nnconv_fused", P(x), H, P(ea), P(w1), P(b1), P(g.rowptr), P(g.col),
+                                              P(g.eid), P(g.invdeg), 0, P(wp), P(bias), P(out), N, H, D),
+        conv_in + N * H * 4 + KT * H * 4, 2.0 * N * KT * H, "mfma")
+    add("nnconv_fused_bwd_x", lambda: _lib.call("qot_nnconv_fused", P(gout), H, P(ea), P(w1), P(b1), P(g.rowptr_t),
+                                                P(g.col_t), P(g.eid_t), P(g.invdeg), 1, P(wp), None, P(out), N, H, D),
+        conv_in + N * H * 4 + KT * H * 4, 2.0 * N * KT * H, "mfma")
+    add("nnconv_gradh_fused", lambda: _lib.call("qot_nnconv_gradh_fused", P(gout), H, P(x), H, P(ea), P(w1), P(b1),
+                                                P(g.rowptr), P(g.col), P(g.eid), P(g.invdeg), P(bp), P(gw1), P(gb1),
+                                                P(ws_h), N, H, D),
+        conv_in + N * H * 4 + K * H * H * 4, 2.0 * N * H * K * H + 2.0 * E * K * H, "mfma")
+    add("nnconv_agg(A for dW)", lambda: _lib.call("qot_nnconv_agg", P(x), H, P(ea), P(w1), P(b1), P(g.rowptr), P(g.col),
+                                                  P(g.eid), None, P(g.invdeg), 0, P(A), N, H, D),
+        conv_in + N * KT * 4)
+    add("gemm_tn(dWcat)", lambda: gemm_tn(A, gout), N * KT * 4 + N * H * 4 + KT * H * 4, 2.0 * N * KT * H, "mfma")
     add("tconv_fwd", lambda: _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H),
                                        4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), P(out), P(stats), N, H, D),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
@@ -177,16 +196,7 @@ def kernel_table(model, batch):
     add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), off(qkvs, 0), 4 * H, P(escr), P(delta),
                                            P(g.rowptr_t), P(g.col_t), P(g.pos_t), off(gq, H), off(gq, 2 * H), 4 * H, N, H),
         2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)
-    add("nnconv_agg_fwd", lambda: _lib.call("qot_nnconv_agg", P(x), H, P(ea), P(w1), P(b1), P(g.rowptr), P(g.col),
-                                            P(g.eid), None, P(g.invdeg), 0, P(A), N, H, D),
-        N * H * 4 + N * (K + 2) * H * 4 + E * D * 4 + csr + 4 * E + 4 * N)
-    add("nnconv_agg_bwd", lambda: _lib.call("qot_nnconv_agg", P(gout), H, P(ea), P(w1), P(b1), P(g.rowptr_t),
-                                            P(g.col_t), P(g.pos_t), P(g.eid), P(g.invdeg), 1, P(A), N, H, D),
-        N * H * 4 + N * (K + 2) * H * 4 + E * D * 4 + csr + 8 * E + 4 * N)
-    add("nnconv_bwd_edge", lambda: _lib.call("qot_nnconv_bwd_edge", P(GA), K * H, P(x), H, P(ea), P(w1), P(b1),
-                                             P(g.rowptr), P(g.col), P(g.eid), P(g.invdeg), P(gw1), P(gb1), N, H, D),
-        N * K * H * 4 + N * H * 4 + E * D * 4 + csr + 4 * E + 4 * N)
-    add("csr_build", lambda: build_graph_index(batch.edge_index, N), 16 * E + 7 * 4 * E + 3 * 4 * N)
+    add("csr_build", lambda: build_graph_index(batch.edge_index, N), 16 * E + 8 * 4 * E + 3 * 4 * N)
     return rows
 
 
@@ -286,9 +296,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["kernel"])
-        res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
-                           "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
+        if dom["bound"] == "mfma":
+            res["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                               "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": dom["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                               "alg_flops_per_launch": dom["flops"], "alg_bytes_per_launch": dom["alg_bytes"],
+                               "ms_per_launch": dom["ms"]}
+        else:
+            res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
+                               "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
         res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)

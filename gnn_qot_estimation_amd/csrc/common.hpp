@@ -73,6 +73,16 @@ __device__ __forceinline__ float wave_sum_partials(const float* __restrict__ par
     return s;
 }
 
+// XCD-aware block remap (bijective for any grid size).  Blocks are dealt round-robin over the 8
+// XCDs, each with a private L2; consecutive row blocks share gathered source rows (same graph),
+// so give every XCD a CONTIGUOUS range of row blocks.  Speed only -- any placement is correct.
+__device__ __forceinline__ int xcd_block(int orig, int nwg) {
+    const int nx = 8;
+    const int q = nwg / nx, r = nwg % nx;
+    const int xcd = orig % nx, idx = orig / nx;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 inline int grid_for(int64_t work, int per_block) { return (int)((work + per_block - 1) / per_block); }
 
 }  // namespace qot

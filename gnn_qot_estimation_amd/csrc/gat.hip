@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
     float ns) {
     using G = GatCfg<HEADS, C>;
     const int sub = threadIdx.x % G::TPR;
-    const int64_t i = (int64_t)blockIdx.x * G::RPB + threadIdx.x / G::TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
     if (i >= N) return;
     int hh[G::NV];
     float ad[G::NV], m[G::NV], l[G::NV];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
     float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns) {
     using G = GatCfg<HEADS, C>;
     const int sub = threadIdx.x % G::TPR;
-    const int64_t i = (int64_t)blockIdx.x * G::RPB + threadIdx.x / G::TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
     if (i >= N) return;
     int hh[G::NV];
     float ad[G::NV], m[G::NV], inv[G::NV], sada[G::NV], sal[G::NV], salk[G::NV];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
     float ns) {
     using G = GatCfg<HEADS, C>;
     const int sub = threadIdx.x % G::TPR;
-    const int64_t j = (int64_t)blockIdx.x * G::RPB + threadIdx.x / G::TPR;
+    const int64_t j = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
     if (j >= N) return;
     int hh[G::NV];
     float as[G::NV], sds[G::NV];

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void nnconv_agg_kernel(
     constexpr int RPB = 256 / TPR;
     constexpr int LDA = (K + 2) * H;
     const int sub = threadIdx.x % TPR;
-    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     if (i >= N) return;
     const int c0 = 4 * sub;
 
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void nnconv_bwd_edge_kernel(
     __syncthreads();
 
     const int sub = threadIdx.x % TPR;
-    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     const int c0 = 4 * sub;
     if (i < N) {
         float w[K][D], b[K];

@@ -148,6 +148,24 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// XCD-aware persistent tile walk.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+// labels the XCD group -- speed only, never correctness), and each XCD has a private L2.  A graph's
+// rows are gathered by the 3-4 consecutive tiles that hold its destinations, so every XCD group
+// walks its own contiguous eighth of the tiles: the rows a tile gathers are then already in that
+// XCD's L2 from the neighbouring tile.  Returns the tile of iteration `it` (or -1 when done).
+__device__ __forceinline__ int64_t xcd_tile(int64_t it, int64_t ntiles) {
+    const int nx = 8;
+    if ((int)gridDim.x % nx != 0) {                        // small grids: plain strided walk
+        const int64_t t = (int64_t)blockIdx.x + it * gridDim.x;
+        return t < ntiles ? t : -1;
+    }
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, per_x = gridDim.x / nx;
+    const int64_t chunk = (ntiles + nx - 1) / nx;
+    const int64_t local = slot + it * per_x;
+    const int64_t t = xcd * chunk + local;
+    return (local < chunk && t < ntiles) ? t : -1;
+}
+
 // diagnostic build only (VARIANT 3): per-phase cycle sums, one adder per wave
 __device__ unsigned long long g_stamps[8];
 #define QOT_STAMP(slot)                                                              \
@@ -172,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     // persistent: 2 workgroups per CU walk the tiles; the two CU-mates drift out of phase so
     // one gathers while the other owns the MFMA pipes
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t it = 0;; ++it) {
+    const int64_t tile = xcd_tile(it, ntiles);
+    if (tile < 0) break;
     const int64_t tile0 = tile * 32;
     float4 root0, root1;
     unsigned long long t_prev = 0;
@@ -321,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
     }
 
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t it = 0;; ++it) {
+        const int64_t tile = xcd_tile(it, ntiles);
+        if (tile < 0) break;
         const int64_t tile0 = tile * 32;
         const int64_t i = tile0 + il;
         // 1. g tile -> LDS (fragment-grouped, group index = sub)

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
-    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     if (i >= N) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
-    const int64_t i = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     if (i >= N) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
-    const int64_t j = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    const int64_t j = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     if (j >= N) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
