@@ -187,14 +187,15 @@ def kernel_table(model, batch):
         conv_in + N * KT * 4)
     add("gemm_tn(dWcat)", lambda: gemm_tn(A, gout), N * KT * 4 + N * H * 4 + KT * H * 4, 2.0 * N * KT * H, "mfma")
     add("tconv_fwd", lambda: _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H),
-                                       4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), P(out), P(stats), N, H, D),
+                                       4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), None, P(out), P(stats), N, H, D),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
-                                           4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), off(gq, 0),
-                                           4 * H, P(escr), P(delta), P(pds), P(pal), N, H, D),
+                                           4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,
+                                           off(gq, 0), 4 * H, P(escr), P(delta), P(pds), P(pal), N, H, D),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 8 * E + 4 * N + 8 * N * D)
     add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), off(qkvs, 0), 4 * H, P(escr), P(delta),
-                                           P(g.rowptr_t), P(g.col_t), P(g.pos_t), off(gq, H), off(gq, 2 * H), 4 * H, N, H),
+                                           P(g.rowptr_t), P(g.col_t), P(g.pos_t), None, off(gq, H), off(gq, 2 * H),
+                                           4 * H, N, H),
         2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)
     add("csr_build", lambda: build_graph_index(batch.edge_index, N), 16 * E + 8 * 4 * E + 3 * 4 * N)
     return rows
@@ -238,10 +239,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 

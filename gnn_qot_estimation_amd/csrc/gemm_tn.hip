@@ -42,12 +42,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const float* __restrict
     auto load = [&](int64_t rbase, float (&a)[S][TPW], float (&b)[S]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            // loads are unconditional (row clamped into the slice) and masked afterwards: a
+            // "load or zero" select makes hipcc branch around every load and drain vmcnt each time
             const int64_t row = rbase + 2 * s + hi;
             const bool ok = row < row1;
-            const float* ar = A + (ok ? row : 0) * lda + r31;
-            b[s] = ok ? G[row * ldg + nh * 32 + r31] : 0.f;
+            const int64_t rc = ok ? row : row1 - 1;
+            const float* ar = A + rc * lda + r31;
+            const float bv = G[rc * ldg + nh * 32 + r31];
+            b[s] = ok ? bv : 0.f;
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) a[s][t] = ok ? ar[(kb0 + 4 * t) * 32] : 0.f;
+            for (int t = 0; t < TPW; ++t) a[s][t] = ar[(kb0 + 4 * t) * 32];
         }
     };
     if (row0 < row1) load(row0, a_cur, b_cur);

@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ skip, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, float* __restrict__ out,
-    float* __restrict__ stats, int64_t N) {
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap,
+    float* __restrict__ out, float* __restrict__ stats, int64_t N) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
@@ -28,8 +28,11 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     if (i >= N) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
+    // table mode: q/k/v/skip are rows of a projected embedding table; rowmap = node -> table row
+    // for this node, and `col` already holds the table row of every in-edge's source
+    const int64_t ri = rowmap ? (int64_t)rowmap[i] : i;
 
-    float4 qi = scale4(rs, ld4(q + i * ld + c0));
+    float4 qi = scale4(rs, ld4(q + ri * ld + c0));
     float wl[4][D];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[c][d], aacc[d] * inv, oc[c]);
-    float4 sk = ld4(skip + i * ld + c0);
+    float4 sk = ld4(skip + ri * ld + c0);
     st4(out + i * H + c0, make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w));
     if (sub == 0) {
         stats[2 * i] = (beg < end) ? m : 0.f;
@@ -95,8 +98,9 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     const float* __restrict__ v, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ eid, float* __restrict__ gq, int ld_g, float* __restrict__ escr,
-    float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal, int64_t N) {
+    const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq, int ld_g,
+    float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
+    int64_t N) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
@@ -104,8 +108,9 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     if (i >= N) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
+    const int64_t ri = rowmap ? (int64_t)rowmap[i] : i;
 
-    float4 qi = scale4(rs, ld4(q + i * ld + c0));
+    float4 qi = scale4(rs, ld4(q + ri * ld + c0));
     float4 gi = ld4(g + i * H + c0);
     float wl[4][D];
 #pragma unroll
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     const float* __restrict__ g, const float* __restrict__ q, int ld,
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
-    const int32_t* __restrict__ pos_t, float* __restrict__ gk, float* __restrict__ gv, int ld_g,
-    int64_t N) {
+    const int32_t* __restrict__ pos_t, const int32_t* __restrict__ qmap_t, float* __restrict__ gk,
+    float* __restrict__ gv, int ld_g, int64_t N) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
         const float a = escr[2 * p], da = escr[2 * p + 1];
         const float ds = a * (da - delta[i]) * rs;
         float4 gi = ld4(g + i * H + c0);
-        float4 qi = ld4(q + i * ld + c0);
+        float4 qi = ld4(q + (qmap_t ? (int64_t)qmap_t[t] : i) * ld + c0);
         av = fma4(a, gi, av);
         ak = fma4(ds, qi, ak);
     }
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
 // phase)), partials[blk, H*D] are then summed in a fixed order by the last kernel.
 template <int H, int D>
 __global__ __launch_bounds__(256) void tconv_wedge_partial_kernel(
-    const float* __restrict__ q, int ld, const float* __restrict__ g, const float* __restrict__ pds,
-    const float* __restrict__ pal, float* __restrict__ partials, int64_t N) {
+    const float* __restrict__ q, int ld, const int32_t* __restrict__ rowmap, const float* __restrict__ g,
+    const float* __restrict__ pds, const float* __restrict__ pal, float* __restrict__ partials, int64_t N) {
     constexpr int PH = 256 / H;                 // row phases per block
     __shared__ float red[256 * D];
     const int c = threadIdx.x % H, ph = threadIdx.x / H;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void tconv_wedge_partial_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     for (int64_t i = r0 + ph; i < r1; i += PH) {
-        const float qv = q[i * ld + c] * rs, gv = g[i * H + c];
+        const float qv = q[(rowmap ? (int64_t)rowmap[i] : i) * ld + c] * rs, gv = g[i * H + c];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = fmaf(qv, pds[i * D + d], fmaf(gv, pal[i * D + d], acc[d]));
     }
@@ -269,15 +274,15 @@ extern "C" size_t qot_tconv_wedge_workspace_floats(int H, int D) {
     return (size_t)kWedgeBlocks * (size_t)(H > 0 ? H : 0) * (size_t)(D > 0 ? D : 0);
 }
 
-extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const float* grad_out, const float* pds,
-                                    const float* pal, float* grad_w_edge, float* workspace, int64_t N, int H,
-                                    int D, qot_stream_t stream_) {
+extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowmap, const float* grad_out,
+                                    const float* pds, const float* pal, float* grad_w_edge, float* workspace,
+                                    int64_t N, int H, int D, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N <= 0 || !q || !grad_out || !pds || !pal || !grad_w_edge || !workspace) return QOT_ERR_BADARG;
     int blocks = kWedgeBlocks;
     if (N < blocks * 8) blocks = (int)((N + 7) / 8);
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
-        tconv_wedge_partial_kernel<kH, kD><<<blocks, 256, 0, stream>>>(q, ld, grad_out, pds, pal, workspace, N);
+        tconv_wedge_partial_kernel<kH, kD><<<blocks, 256, 0, stream>>>(q, ld, rowmap, grad_out, pds, pal, workspace, N);
     }));
     QOT_LAUNCH_CHECK();
     partial_sum_kernel<<<grid_for(H * D, 4), 256, 0, stream>>>(workspace, blocks, H * D, grad_w_edge);
@@ -287,15 +292,15 @@ extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const float* grad_ou
 
 extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                              const float* edge_attr, const float* w_edge, const int32_t* rowptr,
-                             const int32_t* col, const int32_t* eid, float* out, float* stats,
-                             int64_t N, int H, int D, qot_stream_t stream) {
+                             const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
+                             float* stats, int64_t N, int H, int D, qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!q || !k || !v || !skip || !out || !stats || !w_edge || (ld & 3)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, out, stats, N);
+            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N);
     }));
     QOT_LAUNCH_CHECK();
     return QOT_OK;
@@ -304,8 +309,9 @@ extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, con
 extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v,
                                  int ld, const float* edge_attr, const float* w_edge,
                                  const float* stats, const int32_t* rowptr, const int32_t* col,
-                                 const int32_t* eid, float* grad_q, int ld_g, float* escr, float* delta,
-                                 float* pds, float* pal, int64_t N, int H, int D, qot_stream_t stream) {
+                                 const int32_t* eid, const int32_t* rowmap, float* grad_q, int ld_g,
+                                 float* escr, float* delta, float* pds, float* pal, int64_t N, int H, int D,
+                                 qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!grad_out || !q || !k || !v || !stats || !grad_q || !delta || !pds || !pal || (ld & 3) || (ld_g & 3))
@@ -313,7 +319,7 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_bwd_dst_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, grad_q, ld_g, escr,
+            grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, ld_g, escr,
             delta, pds, pal, N);
     }));
     QOT_LAUNCH_CHECK();
@@ -322,15 +328,15 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
 
 extern "C" int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
                                  const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
-                                 const int32_t* pos_t, float* grad_k, float* grad_v, int ld_g, int64_t N,
-                                 int H, qot_stream_t stream) {
+                                 const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
+                                 int ld_g, int64_t N, int H, qot_stream_t stream) {
     if (N < 0 || !rowptr_t) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!grad_out || !q || !delta || !grad_k || !grad_v || (ld & 3) || (ld_g & 3)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_bwd_src_kernel<kH><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            grad_out, q, ld, escr, delta, rowptr_t, col_t, pos_t, grad_k, grad_v, ld_g, N);
+            grad_out, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -88,51 +88,72 @@ class LinearFn(torch.autograd.Function):
 class TConvFn(torch.autograd.Function):
     """Fused edge-softmax-aggregate of TransformerConv on packed projections.
 
-    ``qkvs`` is ``[N, 4H]`` = ``[q | k | v | skip]`` (one GEMM); returns ``[N, H]``.
+    ``qkvs`` is ``[R, 4H]`` = ``[q | k | v | skip]`` (one GEMM); returns ``[N, H]``.
+    Node mode (``maps is None``): R == N, one projected row per node.
+    Table mode (``maps = (rowmap, colf, colf_t, tiles)``): ``qkvs`` is the projected EMBEDDING TABLE
+    ``[V, 4H]`` and rows are gathered through ``node_ids`` -- ``(emb W^T + b)[ids]`` equals
+    ``emb[ids] W^T + b`` (``topological_training/models.py:51-53``), so the four node-level GEMMs
+    and the embedding gather/scatter disappear and the kernels' inputs are L2-resident.
+    ``tiles = (B, n)``: node_ids is ``arange(n)`` repeated B times, so the table gradient is the sum
+    over graphs of the per-node gradient ``[B, n, 4H]``.
     """
 
     @staticmethod
-    def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex):
+    def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex, maps):
         require_cuda(qkvs, edge_attr, w_edge)
         qkvs, edge_attr, w_edge = _f32c(qkvs), _f32c(edge_attr), _f32c(w_edge)
-        N, H4 = qkvs.shape
+        H4 = qkvs.shape[1]
         H = H4 // 4
         D = w_edge.shape[1]
+        N = graph.num_nodes
+        if maps is None and qkvs.shape[0] != N:
+            raise ValueError("qkvs must have one row per node")
         if edge_attr.shape != (graph.num_edges_in, D):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
+        rowmap, colf = (maps[0], maps[1]) if maps is not None else (None, graph.col)
         out = torch.empty(N, H, dtype=torch.float32, device=qkvs.device)
         stats = torch.empty(N, 2, dtype=torch.float32, device=qkvs.device)
         _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
-                  P(edge_attr), P(w_edge), P(graph.rowptr), P(graph.col), P(graph.eid), P(out), P(stats),
+                  P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
                   N, H, D)
         ctx.save_for_backward(qkvs, edge_attr, w_edge, stats)
-        ctx.graph = graph
+        ctx.graph, ctx.maps = graph, maps
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkvs, edge_attr, w_edge, stats = ctx.saved_tensors
-        graph = ctx.graph
+        graph, maps = ctx.graph, ctx.maps
         g = _f32c(g)
-        N, H4 = qkvs.shape
+        H4 = qkvs.shape[1]
         H = H4 // 4
         D = w_edge.shape[1]
+        N = graph.num_nodes
         dev = qkvs.device
-        gqkvs = torch.empty(N, H4, dtype=torch.float32, device=dev)
+        rowmap, colf, colf_t = (maps[0], maps[1], maps[2]) if maps is not None else (None, graph.col, None)
+        gnode = torch.empty(N, H4, dtype=torch.float32, device=dev)        # per-node [gq | gk | gv | gskip]
         escr = torch.empty(max(graph.cap, 1), 2, dtype=torch.float32, device=dev)
         delta = torch.empty(N, dtype=torch.float32, device=dev)
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
-                  P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(graph.col), P(graph.eid),
-                  _off(gqkvs, 0), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
+                  P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap),
+                  _off(gnode, 0), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
         _lib.call("qot_tconv_bwd_src", P(g), _off(qkvs, 0), H4, P(escr), P(delta), P(graph.rowptr_t),
-                  P(graph.col_t), P(graph.pos_t), _off(gqkvs, H), _off(gqkvs, 2 * H), H4, N, H)
-        gqkvs[:, 3 * H:] = g
+                  P(graph.col_t), P(graph.pos_t), P(colf_t), _off(gnode, H), _off(gnode, 2 * H), H4, N, H)
+        gnode[:, 3 * H:] = g
         gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_tconv_wedge_workspace_floats(H, D), dtype=torch.float32, device=dev)
-        _lib.call("qot_tconv_wedge_grad", _off(qkvs, 0), H4, P(g), P(pds), P(pal), P(gwe), P(ws), N, H, D)
-        return gqkvs, None, gwe, None
+        _lib.call("qot_tconv_wedge_grad", _off(qkvs, 0), H4, P(rowmap), P(g), P(pds), P(pal), P(gwe), P(ws),
+                  N, H, D)
+        if maps is None:
+            gq = gnode
+        else:
+            B, n = maps[3]
+            gq = gnode.view(B, n * H4).sum(0).view(n, H4)     # table rows = sum over graphs
+            if n < qkvs.shape[0]:                              # table rows no node refers to
+                gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
+        return gq, None, gwe, None, None
 
 
 # ------------------------------------------------------------------ NNConv (a4)

@@ -141,3 +141,29 @@ def cached_i32(data, name: str) -> torch.Tensor:
     if c is not None:
         c[key] = (tag, out)
     return out
+
+
+def table_maps_for(data, graph: GraphIndex, ids32: torch.Tensor):
+    """(rowmap, colf, colf_t, (B, n)) for TransformerConv's table mode, or None.
+
+    Table mode needs ``node_ids == arange(n)`` repeated for every graph (what the reference's
+    dataset emits: ``topological_training/dataset.py:78``) -- then the gradient of the projected
+    table is a plain sum over graphs.  The batch object advertises it as ``uniform_node_ids = n``
+    (set by ``Batch.from_data_list`` on the host); otherwise the general per-node path runs.
+    """
+    n = getattr(data, "uniform_node_ids", None)
+    if not n:
+        return None
+    N = graph.num_nodes
+    if N % n != 0:
+        return None
+    tag = (ids32.data_ptr(), graph.col.data_ptr())
+    c = _cache(data)
+    if c is not None and "tmaps" in c and c["tmaps"][0] == tag:
+        return c["tmaps"][1]
+    colf = ids32.index_select(0, graph.col.long()[:max(graph.cap, 1)].clamp_(0, max(N - 1, 0)))
+    colf_t = ids32.index_select(0, graph.col_t.long()[:max(graph.cap, 1)].clamp_(0, max(N - 1, 0)))
+    res = (ids32, colf.contiguous(), colf_t.contiguous(), (N // n, int(n)))
+    if c is not None:
+        c["tmaps"] = (tag, res)
+    return res

@@ -58,7 +58,14 @@ class TransformerConv(nn.Module):
             graph = build_graph_index(edge_index, x.shape[0])
         w, b = self.packed_weight()
         qkvs = QF.LinearFn.apply(x, w, b)             # one MFMA GEMM for q|k|v|skip
-        return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph)
+        return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph, None)
+
+    def forward_table(self, table, edge_attr, graph: GraphIndex, maps):
+        """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
+        ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows."""
+        w, b = self.packed_weight()
+        t4 = F.linear(table, w, b)                    # [V, 4H]
+        return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps)
 
 
 class NNConv(nn.Module):

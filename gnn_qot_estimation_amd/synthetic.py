@@ -127,6 +127,7 @@ def tile_batch(base: Batch, times: int) -> Batch:
     n, b = base.num_nodes, base.num_graphs
     out = Batch()
     out.num_graphs = b * times
+    out.uniform_node_ids = getattr(base, "uniform_node_ids", None)
     out._num_nodes = n * times
     out.ptr = torch.cat([base.ptr[:-1] + k * n for k in range(times)] + [torch.tensor([n * times])])
     out.batch = torch.cat([base.batch + k * b for k in range(times)])

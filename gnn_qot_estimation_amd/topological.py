@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import functional as QF
-from .graph import batch_index_for, cached_i32, graph_index_for
+from .graph import batch_index_for, cached_i32, graph_index_for, table_maps_for
 from .nn import NNConv, TransformerConv
 
 
@@ -55,17 +55,26 @@ class TopologicalGNN(nn.Module):
 
     def forward(self, data):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        maps = None
         if x is None or x.numel() == 0:
             n = data.node_ids.shape[0]
-            x = QF.EmbedFn.apply(self.node_embeddings.weight, cached_i32(data, "node_ids"))
+            graph = graph_index_for(data, n)
+            ids32 = cached_i32(data, "node_ids")
+            maps = table_maps_for(data, graph, ids32)
+            if maps is None:
+                x = QF.EmbedFn.apply(self.node_embeddings.weight, ids32)
         else:
             n = x.shape[0]
-        graph = graph_index_for(data, n)
+            graph = graph_index_for(data, n)
         step = None
         if self.training and self.dropout.p > 0.0:
             self._qot_step.add_(1)
             step = self._qot_step.clone()   # this forward's draw; backward re-reads the clone
-        x = self._act(self.conv1(x, edge_index, edge_attr, graph=graph), 0, step)
+        if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
+            x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps)
+        else:
+            x = self.conv1(x, edge_index, edge_attr, graph=graph)
+        x = self._act(x, 0, step)
         for layer in range(2, self.num_layers + 1):
             x = self._act(getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph), layer - 1, step)
         b32, ptr, B = batch_index_for(data, n)

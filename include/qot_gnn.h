@@ -88,30 +88,35 @@ int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, 
  * fwd: out_i = sum_e softmax_e(<q_i, k_j + We ea_e>/sqrt(H)) (v_j + We ea_e) + skip_i
  * stats[N,2] = (max logit, denominator incl. 1e-16) saved for backward.
  * edge_attr is in ORIGINAL edge order ([E,D]); the kernels index it through eid.
+ * Table mode (rowmap != NULL): q/k/v/skip are rows of a PROJECTED EMBEDDING TABLE [V, 4H]
+ * ((emb W^T + b)[node_ids] == (emb[node_ids]) W^T + b, topological_training/models.py:51-53);
+ * rowmap[i] = table row of node i and `col` must then hold the table row of each in-edge's source
+ * (node_ids[col]).  NULL: one row per node, as produced by a node-level GEMM.
  */
 int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                   const float* edge_attr, const float* w_edge, const int32_t* rowptr,
-                  const int32_t* col, const int32_t* eid, float* out, float* stats, int64_t N,
-                  int H, int D, qot_stream_t stream);
+                  const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
+                  float* stats, int64_t N, int H, int D, qot_stream_t stream);
 /* bwd, destination pass: grad_q[N,H] (ld_g), per-edge scratch escr[cap,2] = (alpha, dalpha),
  * delta[N], pds[N,D] = sum_e ds_e ea_e, pal[N,D] = sum_e alpha_e ea_e. */
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,
-                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, float* grad_q,
-                      int ld_g, float* escr, float* delta, float* pds, float* pal, int64_t N, int H,
-                      int D, qot_stream_t stream);
-/* bwd, source pass: grad_k, grad_v [N,H] (ld_g). */
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                      const int32_t* rowmap, float* grad_q, int ld_g, float* escr, float* delta,
+                      float* pds, float* pal, int64_t N, int H, int D, qot_stream_t stream);
+/* bwd, source pass: grad_k, grad_v [N,H] (ld_g).  qmap_t (table mode, else NULL): table row of
+ * each out-edge's destination (node_ids[col_t]) for the q gather; grad_out/delta stay per node. */
 int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
                       const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
-                      const int32_t* pos_t, float* grad_k, float* grad_v, int ld_g, int64_t N, int H,
-                      qot_stream_t stream);
+                      const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
+                      int ld_g, int64_t N, int H, qot_stream_t stream);
 
 /* grad of lin_edge.weight: gWe[H,D] = (q/sqrt(H))^T pds + grad_out^T pal  (deterministic two-stage
  * column reduction; workspace: qot_tconv_wedge_workspace_floats(H, D) floats). */
 size_t qot_tconv_wedge_workspace_floats(int H, int D);
-int qot_tconv_wedge_grad(const float* q, int ld, const float* grad_out, const float* pds,
-                         const float* pal, float* grad_w_edge, float* workspace, int64_t N, int H, int D,
-                         qot_stream_t stream);
+int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowmap, const float* grad_out,
+                         const float* pds, const float* pal, float* grad_w_edge, float* workspace,
+                         int64_t N, int H, int D, qot_stream_t stream);
 
 /* ---- NNConv (aggr = mean), factorised ----------------------------------------------
  * h_e = relu(W1 ea_e + b1) in R^K, K = 2D.  Builds the GEMM operand

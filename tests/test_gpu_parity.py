@@ -234,3 +234,41 @@ def test_colsum(cuda_device):
     from gnn_qot_estimation_amd.functional import colsum
     x = torch.randn(10007, 256, device=cuda_device)
     assert rel_err(colsum(x), x.double().sum(0)) <= 1e-5
+
+
+def test_topological_mixed_sizes_uses_node_path(cuda_device):
+    """Graphs of different sizes: no uniform node_ids hint -> per-node embedding path (EmbedFn +
+    node-level projections) instead of TransformerConv's table mode; both must match the oracle."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    a = S.topological_batch(2, 1, n=10, e=24)
+    b = S.topological_batch(2, 1, n=14, e=30, first_graph=5)
+    g1 = q.Data(edge_index=a.edge_index, edge_attr=a.edge_attr, node_ids=a.node_ids, y=a.y, num_nodes=10)
+    g2 = q.Data(edge_index=b.edge_index, edge_attr=b.edge_attr, node_ids=b.node_ids, y=b.y, num_nodes=14)
+    batch = q.Batch.from_data_list([g1, g2, g1])
+    assert batch.uniform_node_ids is None
+    ref, hip = _models("topo", cuda_device, num_nodes=14, hidden_channels=64, out_channels=3, edge_dim=4, dropout_p=0.0)
+    out_ref = ref(batch)
+    out_hip = hip(batch.to(cuda_device))
+    assert rel_err(out_hip, out_ref) <= TOL
+    y = batch.y.view(-1, 3)
+    torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
+    torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip)
+
+
+def test_table_mode_is_used_and_table_larger_than_graph(cuda_device):
+    """uniform node_ids -> table mode; embedding table with more rows than the graphs use
+    (V = 75 rows, 14-node graphs): unused rows get exactly zero gradient."""
+    from gnn_qot_estimation_amd import synthetic as S
+    batch = S.topological_batch(1, 6)
+    assert batch.uniform_node_ids == 14
+    ref, hip = _models("topo", cuda_device, num_nodes=75, hidden_channels=32, out_channels=3, edge_dim=4, dropout_p=0.0)
+    out_ref = ref(batch)
+    out_hip = hip(batch.to(cuda_device))
+    assert rel_err(out_hip, out_ref) <= TOL
+    y = batch.y.view(-1, 3)
+    torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
+    torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip)
+    assert float(hip.node_embeddings.weight.grad[14:].abs().max()) == 0.0
