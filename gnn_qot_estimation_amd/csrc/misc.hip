@@ -189,17 +189,28 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
     }
 }
 
+// one wave per column: lanes stride over the per-block partials (fp64), fixed shuffle tree
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 __global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const float* __restrict__ partials,
                                          int nblk, int64_t N, int C, float eps, float momentum,
                                          float* __restrict__ mean, float* __restrict__ rstd,
                                          float* __restrict__ rmean, float* __restrict__ rvar) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s1 += (double)partials[((int64_t)b * 2) * C + c];
         s2 += (double)partials[((int64_t)b * 2 + 1) * C + c];
     }
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+    if (lane) return;
     double dn = (double)N;
     double m1 = s1 / dn;
     double var = s2 / dn - m1 * m1;
@@ -216,15 +227,17 @@ __global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const floa
 
 __global__ void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nblk, int C,
                                        float* __restrict__ gw, float* __restrict__ gb) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = threadIdx.x & 63;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s1 += (double)partials[((int64_t)b * 2) * C + c];
         s2 += (double)partials[((int64_t)b * 2 + 1) * C + c];
     }
-    gb[c] = (float)s1;
-    gw[c] = (float)s2;
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+    if (lane == 0) { gb[c] = (float)s1; gw[c] = (float)s2; }
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -455,7 +468,7 @@ extern "C" int qot_bn_stats(const float* x, int64_t N, int C, float eps, float m
     int nblk = bn_blocks(N);
     bn_partial_kernel<0><<<nblk, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, nullptr, partials, N, C, 0);
     QOT_LAUNCH_CHECK();
-    bn_finalize_stats_kernel<<<grid_for(C, 256), 256, 0, stream>>>(x, partials, nblk, N, C, eps, momentum, mean, rstd, running_mean, running_var);
+    bn_finalize_stats_kernel<<<grid_for(C, 4), 256, 0, stream>>>(x, partials, nblk, N, C, eps, momentum, mean, rstd, running_mean, running_var);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }
@@ -481,7 +494,7 @@ extern "C" int qot_bn_bwd_reduce(const float* grad_y, const float* y, const floa
     int nblk = bn_blocks(N);
     bn_partial_kernel<1><<<nblk, 256, 0, stream>>>(x, grad_y, y, mean, rstd, partials, N, C, relu);
     QOT_LAUNCH_CHECK();
-    bn_finalize_bwd_kernel<<<grid_for(C, 256), 256, 0, stream>>>(partials, nblk, C, gw, gb);
+    bn_finalize_bwd_kernel<<<grid_for(C, 4), 256, 0, stream>>>(partials, nblk, C, gw, gb);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

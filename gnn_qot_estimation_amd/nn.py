@@ -136,9 +136,13 @@ class GATConv(nn.Module):
         if not graph.gat_self_loops:
             raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
         z = self.lin(x)
-        zv = z.view(n, h, c)
-        a_src = (zv * self.att_src).sum(-1)
-        a_dst = (zv * self.att_dst).sum(-1)
+        # attention logits: a[n,h] = sum_c z[n,h,c] att[h,c] = x[n,:] . (sum_c W[h,c,:] att[h,c]).
+        # Folding att into the projection weight turns two [N, heads*C] elementwise passes +
+        # reductions (and their autograd copies) into one skinny GEMM [N,F] x [F, 2*heads].
+        w3 = self.lin.weight.view(h, c, self.in_channels)
+        w_att = torch.cat([(w3 * self.att_src.view(h, c, 1)).sum(1), (w3 * self.att_dst.view(h, c, 1)).sum(1)], 0)
+        a = x @ w_att.t()                                # [N, 2*heads]
+        a_src, a_dst = a[:, :h].contiguous(), a[:, h:].contiguous()
         return QF.GatFn.apply(z, a_src, a_dst, self.bias, graph, self.negative_slope)
 
 

@@ -1,0 +1,71 @@
+"""Train-step throughput on BASELINE.json's other configs (not bench lines: evidence for the
+kernels the headline config does not exercise -- GAT/BN/LUT, H = 32/128/256, power-law degrees).
+Eager launches, events around K steps, batch resident in HBM, CSR build inside every step."""
+import json, os, sys, time
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gnn_qot_estimation_amd as q
+from gnn_qot_estimation_amd import synthetic as S
+from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+
+dev = torch.device("cuda:0")
+
+
+def run(name, model, batch, loss_fn, steps=10, warm=3):
+    model.to(dev).train()
+    flat = FlatModel(model)
+    opt = FusedSGD(flat, lr=0.01, momentum=0.9)
+
+    def step():
+        batch._qot_cache = {}
+        flat.detach_grads()
+        loss = loss_fn(model, batch)
+        loss.backward()
+        flat.gather_grads()
+        opt.step()
+        return loss
+    for _ in range(warm):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lv = float(loss)
+    assert lv == lv, "non-finite loss"
+    row = dict(config=name, graphs=batch.num_graphs, nodes=batch.num_nodes, edges=batch.num_edges,
+               ms_per_step=round(dt * 1e3, 3), graphs_per_s=round(batch.num_graphs / dt), loss=round(lv, 5),
+               mem_GB=round(torch.cuda.max_memory_allocated() / 2**30, 2))
+    print(json.dumps(row), flush=True)
+    return row
+
+
+def topo_loss(m, b):
+    return F.smooth_l1_loss(m(b), b.y.view(-1, 3))
+
+
+def lp_loss(m, b):
+    out, lb = m(b)
+    return F.smooth_l1_loss(out, b.y[lb])
+
+
+which = sys.argv[1:] or ["cfg1", "ref_topo", "ref_lp", "cfg3", "cfg4", "cfg5"]
+torch.manual_seed(0)
+if "cfg1" in which:   # plumbing config (runs on GPU here; the reference runs it on CPU)
+    run("cfg1: NSFNET 14n, H=32, B=16", q.TopologicalGNN(14, 32, 3, 4), S.topological_batch(1, 16).to(dev), topo_loss)
+if "ref_topo" in which:   # the literal reference scale: V=75, H=16, B=512 (train.py:38,50-51)
+    b = S.tile_batch(S.topological_batch(2, 64, n=75, e=60), 8).to(dev)
+    run("reference scale topological: V=75 H=16 B=512", q.TopologicalGNN(75, 16, 3, 4), b, topo_loss)
+if "ref_lp" in which:     # F=5, C=32, B=512 (lightpath_training/train.py:39,52)
+    run("reference scale lightpath: F=5 C=32 B=512", q.LightpathGNN(5, 32, 3, 1), S.lightpath_batch(512).to(dev), lp_loss)
+if "cfg3" in which:
+    b = S.tile_batch(S.lightpath_batch(1024), 64).to(dev)          # 65 536 graphs
+    run("cfg3: lightpath 65536 graphs, 3-layer C=128", q.LightpathGNN(5, 128, 3, 1, num_layers=3), b, lp_loss, steps=5, warm=2)
+if "cfg4" in which:
+    b = S.tile_batch(S.topological_batch(4, 32, n=1000, e=4000), 32).to(dev)   # one GPU's share: 1024 graphs
+    run("cfg4 per-GPU share: 1024 x (1000n/4000e), 3-layer H=128", q.TopologicalGNN(1000, 128, 3, 4, num_layers=3), b, topo_loss, steps=3, warm=1)
+if "cfg5" in which:
+    b = S.tile_batch(S.topological_batch(5, 16, n=1000), 16).to(dev)           # 256 power-law graphs
+    run("cfg5 (256 graphs): power-law max in-degree 64, H=256", q.TopologicalGNN(1000, 256, 3, 4), b, topo_loss, steps=3, warm=1)
