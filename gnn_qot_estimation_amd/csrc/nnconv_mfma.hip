@@ -294,6 +294,232 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of NNConv, data AND weight gradients from ONE gather  (H = 64).
+//   U_j = [ sum_{e: j->i} h_e[k] invdeg_i g_i (k<K) | sum_e invdeg_i g_i | g_j ]     (adjoint tile)
+//   grad_x_j  = U_j @ WcatT                         (as nnconv_mfma64<TRANSPOSE>)
+//   gWcat     = sum_j x_j (x) U_j  ("X^T U")        -- grad of nn.2.weight / nn.2.bias / lin.weight
+// The separate path re-gathered the forward operand A ([N,640] = 262 MB written, then read by a
+// split-K GEMM).  Here the U tile that the adjoint needs anyway is multiplied twice: rows as the
+// A operand (grad_x) and, read transposed from the same LDS image, against the tile's own x rows
+// (weight gradient).  512 threads = 8 waves, one workgroup per CU: every wave keeps 5 of the 40
+// 32x32 accumulator tiles of gWcat^T across the persistent loop (80 VGPRs), partials go to one slab
+// per workgroup and are summed in a fixed order afterwards (bitwise reproducible).
+constexpr int kAdjBlocksPerCu = 1;
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
+    const float* __restrict__ g, int ldg, const float* __restrict__ xf, int ldx, const float* __restrict__ ea,
+    const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr_t,
+    const int32_t* __restrict__ col_t, const int32_t* __restrict__ eid_t, const float* __restrict__ invdeg,
+    const float* __restrict__ Wp, float* __restrict__ gx, float* __restrict__ slabs, int64_t N) {
+    constexpr int K = 2 * D;
+    constexpr int KT = (K + 2) * 64;        // all K+2 blocks live in LDS (one workgroup per CU: room)
+    constexpr int GQ = KT / 8 / 4;          // float4 groups per K quarter (20 at D=4)
+    constexpr int MB = KT / 32;             // 32-row blocks of gWcat^T (20)
+    constexpr int TPW = MB * 2 / 8;         // dW tiles per wave (5)
+    static_assert(GQ % 4 == 0 || GQ % 5 == 0, "chunking");
+    constexpr int CH = (GQ % 5 == 0) ? 5 : 4;
+    __shared__ __attribute__((aligned(16))) float Ut[KT * 32];
+    __shared__ __attribute__((aligned(16))) float red[8 * 3 * 4 * 64];
+    float4* Ut4 = reinterpret_cast<float4*>(Ut);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int nh = wave & 1, kq = wave >> 1;                 // grad_x: column half x K quarter
+    const int ah = wave & 1, mb0 = wave >> 1;                // dW: x-channel half, row blocks mb0 + 4t
+    const int64_t ntiles = (N + 31) / 32;
+
+    f32x16 dw[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[t][r] = 0.f;
+    // transposed-read addressing of the U tile for this lane's dW rows (kcol = 32*mb + r31)
+    int dwbase[TPW], dwmask[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int kcol = (mb0 + 4 * t) * 32 + r31;
+        const int gg = kcol >> 3, within = kcol & 7;
+        dwbase[t] = ((2 * gg + (within & 1)) * 32) * 4 + (within >> 1);
+        dwmask[t] = gg & 7;
+    }
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nh * (KT / 8) + kq * GQ) * 64 + lane;
+
+#pragma unroll 1
+    for (int64_t it = 0;; ++it) {
+        const int64_t tile = xcd_tile(it, ntiles);
+        if (tile < 0) break;
+        const int64_t tile0 = tile * 32;
+        // ---- gather: 16 lanes per source node j (float4 = 64 channels), out-edges over the CSC
+        {
+            const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
+            const int c0 = 4 * sub;
+            const int64_t j = tile0 + il;
+            float4 acc[K + 2];
+#pragma unroll
+            for (int kk = 0; kk < K + 2; ++kk) acc[kk] = f4zero();
+            int beg = 0, end = 0;
+            if (j < N) { beg = rowptr_t[j]; end = rowptr_t[j + 1]; acc[K + 1] = ld4(g + j * ldg + c0); }
+            for (int base = beg; base < end; base += 16) {
+                const int p = base + sub;
+                int myi = 0;
+                float myh[K], mysc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
+                if (p < end) {
+                    myi = col_t[p];
+                    const int64_t e = eid_t[p];
+                    float ee[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+                    mysc = invdeg[myi];
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) {
+                        float h = b1[kk];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
+                        myh[kk] = fmaxf(h, 0.f) * mysc;
+                    }
+                }
+                const int cnt = (end - base < 16) ? end - base : 16;
+                for (int u0 = 0; u0 < cnt; u0 += 4) {
+                    float4 gr[4];
+                    float sc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = u0 + u;
+                        const int64_t i = __shfl(myi, src, 16);
+                        sc[u] = (src < cnt) ? __shfl(mysc, src, 16) : 0.f;
+                        gr[u] = ld4(g + (src < cnt ? i : 0) * ldg + c0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = u0 + u;
+#pragma unroll
+                        for (int kk = 0; kk < K; ++kk) {
+                            float h = __shfl(myh[kk], src, 16);
+                            if (src >= cnt) h = 0.f;
+                            acc[kk] = fma4(h, gr[u], acc[kk]);
+                        }
+                        acc[K] = fma4(sc[u], gr[u], acc[K]);
+                    }
+                }
+            }
+            // channels c0..c0+3 of block kk: k = 64 kk + c0 + t -> group 8 kk + sub/2,
+            // (r, hi) = (2 (sub&1) + t/2, t&1): two 8-byte stores per block, conflict-free
+#pragma unroll
+            for (int kk = 0; kk < K + 2; ++kk) {
+                const int gg = kk * 8 + (sub >> 1);
+                float2* s0 = reinterpret_cast<float2*>(&Ut4[at4_slot(gg, 0, il)]) + (sub & 1);
+                float2* s1 = reinterpret_cast<float2*>(&Ut4[at4_slot(gg, 1, il)]) + (sub & 1);
+                *s0 = make_float2(acc[kk].x, acc[kk].z);
+                *s1 = make_float2(acc[kk].y, acc[kk].w);
+            }
+        }
+        // x rows of the tile's own nodes (B operand of the weight-gradient product) and the first
+        // WcatT fragments: requested right after the gather's LDS writes, ahead of the barrier
+        // (hoisting them above the gather spilled: the gather needs the registers)
+        float xb[16];
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int64_t j = tile0 + 2 * sidx + hi;
+            const float v = xf[(j < N ? j : N - 1) * ldx + ah * 32 + r31];
+            xb[sidx] = (j < N) ? v : 0.f;
+        }
+        float4 bc[CH], bn[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) bc[u] = wp[u * 64];
+        lds_barrier();
+        // ---- grad_x: this wave's K quarter of U @ WcatT
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        {
+#pragma unroll 1
+            for (int ch = 0; ch < GQ / CH; ++ch) {
+                if (ch + 1 < GQ / CH) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) bn[u] = wp[((ch + 1) * CH + u) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) c = mfma_group(Ut4, kq * GQ + ch * CH + u, hi, r31, bc[u], c);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) bc[u] = bn[u];
+            }
+        }
+        // ---- weight gradient: gWcat^T[(k,o)][a] += sum_j U[j][(k,o)] x[j][a]
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int jj = 2 * sidx + hi;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const float a = Ut[dwbase[t] + ((jj ^ dwmask[t]) << 2)];
+                dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[sidx], dw[t], 0, 0, 0);
+            }
+        }
+        // ---- K quarters of grad_x meet through LDS: quarter q finishes accumulator registers
+        // 4q..4q+3 of its column half (hands the other 12 over), so all 8 waves share the stores.
+        // red[((owner*2 + nh)*3 + slot)*4 + rr][lane], slot = which of the 3 other quarters wrote it
+#define QOT_GIVE(OWNER, SLOT)                                                                        \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr)                                             \
+            red[((((OWNER) * 2 + nh) * 3 + (SLOT)) * 4 + rr) * 64 + lane] = c[4 * (OWNER) + rr];
+        if (kq == 0) { QOT_GIVE(1, 0) QOT_GIVE(2, 0) QOT_GIVE(3, 0) }
+        else if (kq == 1) { QOT_GIVE(0, 0) QOT_GIVE(2, 1) QOT_GIVE(3, 1) }
+        else if (kq == 2) { QOT_GIVE(0, 1) QOT_GIVE(1, 1) QOT_GIVE(3, 2) }
+        else { QOT_GIVE(0, 2) QOT_GIVE(1, 2) QOT_GIVE(2, 2) }
+#undef QOT_GIVE
+        lds_barrier();
+        {
+            float v[4];
+            if (kq == 0) { v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; v[3] = c[3]; }
+            else if (kq == 1) { v[0] = c[4]; v[1] = c[5]; v[2] = c[6]; v[3] = c[7]; }
+            else if (kq == 2) { v[0] = c[8]; v[1] = c[9]; v[2] = c[10]; v[3] = c[11]; }
+            else { v[0] = c[12]; v[1] = c[13]; v[2] = c[14]; v[3] = c[15]; }
+            const int colg = nh * 32 + r31;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                for (int slot = 0; slot < 3; ++slot) v[rr] += red[(((kq * 2 + nh) * 3 + slot) * 4 + rr) * 64 + lane];
+                const int reg = 4 * kq + rr;
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                const int64_t j = tile0 + row;
+                if (j < N) gx[j * 64 + colg] = v[rr];
+            }
+        }
+        lds_barrier();            // Ut / red are rewritten by the next tile
+    }
+    // slab[blk][(k,o) row][a]
+    float* slab = slabs + (int64_t)blockIdx.x * KT * 64;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            slab[((mb0 + 4 * t) * 32 + row) * 64 + ah * 32 + r31] = dw[t][r];
+        }
+}
+
+// level-1/level-2 slab sums (same scheme as gemm_tn.hip; duplicated signature, internal linkage)
+__global__ void adj_slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int per_group, int64_t elems,
+                                       int64_t slab_stride, float* __restrict__ dst, int64_t dst_stride) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t * 4 >= elems) return;
+    const int s0 = blockIdx.y * per_group;
+    int s1 = s0 + per_group;
+    if (s1 > nslabs) s1 = nslabs;
+    float4 acc = f4zero();
+    int sidx = s0;
+    for (; sidx + 8 <= s1; sidx += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld4(slabs + (int64_t)(sidx + u) * slab_stride + 4 * t);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+    }
+    for (; sidx < s1; ++sidx) acc = add4(acc, ld4(slabs + (int64_t)sidx * slab_stride + 4 * t));
+    st4(dst + blockIdx.y * dst_stride + 4 * t, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // grad of the edge MLP's first layer (nn.0.weight / nn.0.bias), fused.
 //   dL/dh_e[k] = invdeg_i * < GA_i[k,:], x_j > ,  GA_i[k,a] = sum_o g_i[o] * W2[a*64+o, k]
 // The unfused path materialises GA ([N, 512] fp32, a 6.7 GFLOP library GEMM measured at 291 us)
@@ -577,6 +803,45 @@ extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const flo
     QOT_LAUNCH_CHECK();
     const int n = K * (D + 1);
     gradh_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, grid, n, K * D, gw1, gb1);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// grad_x + weight gradient of NNConv in one pass (H = 64, D <= 4).  w_perm: WcatT in fragment
+// order (as for qot_nnconv_fused transpose=1).  gwcat_t[(K+2)*64, 64] receives gWcat^T per block:
+// gwcat_t[k*64 + o][a] = d/dWcat[k*64 + a][o].  workspace: qot_nnconv_adjoint_dw_workspace_floats(D).
+extern "C" size_t qot_nnconv_adjoint_dw_workspace_floats(int D) {
+    return (size_t)(num_cus() > 256 ? num_cus() : 256) * kAdjBlocksPerCu * (size_t)((2 * D + 2) * 64) * 64;
+}
+
+extern "C" int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const float* x, int ld_x,
+                                     const float* edge_attr, const float* w1, const float* b1,
+                                     const int32_t* rowptr_t, const int32_t* col_t, const int32_t* eid_t,
+                                     const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t,
+                                     float* workspace, int64_t N, int H, int D, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || !rowptr_t) return QOT_ERR_BADARG;
+    if (H != 64 || D > 4) return QOT_ERR_UNSUPPORTED;
+    if (!grad_out || !x || !w1 || !b1 || !invdeg || !w_perm || !grad_x || !gwcat_t || !workspace || (ld_g & 3))
+        return QOT_ERR_BADARG;
+    int grid = grid_for(N, 32);
+    const int cap = num_cus() * kAdjBlocksPerCu;
+    if (grid > cap) grid = cap;
+    QOT_DISPATCH_D(D, {
+        if (kD <= 4)
+            nnconv_adjoint_dw64_kernel<(kD <= 4 ? kD : 4)><<<grid, 512, 0, stream>>>(
+                grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr_t, col_t, eid_t, invdeg, w_perm, grad_x,
+                workspace, N);
+    });
+    QOT_LAUNCH_CHECK();
+    const int64_t elems = (int64_t)(2 * D + 2) * 64 * 64;
+    const int per_group = 16;
+    const int groups = (grid + per_group - 1) / per_group;
+    adj_slab_reduce_kernel<<<dim3(grid_for(elems / 4, 256), groups), 256, 0, stream>>>(
+        workspace, grid, per_group, elems, elems, workspace, (int64_t)per_group * elems);
+    QOT_LAUNCH_CHECK();
+    adj_slab_reduce_kernel<<<dim3(grid_for(elems / 4, 256), 1), 256, 0, stream>>>(
+        workspace, groups, groups, elems, (int64_t)per_group * elems, gwcat_t, 0);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

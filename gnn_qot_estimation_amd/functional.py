@@ -262,26 +262,36 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         gbias = colsum(g)
-        if A is None:      # fused forward did not materialise the operand: rebuild it for dW
-            A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
-            _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                      P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-        gwcat = gemm_tn(A, g)                                    # [(K+2)Hin, Hout] = A^T g
+        wcat_t = nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        if _fused_ok(hin, hout) and D <= 4 and not os.environ.get("QOT_SPLIT_NNCONV_BWD"):
+            # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U
+            wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
+            gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
+            gwt = torch.empty((K + 2) * hout, hin, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp), P(gx), P(gwt), P(ws), N, hin, D)
+            gwcat = gwt.view(K + 2, hout, hin).transpose(1, 2).reshape((K + 2) * hin, hout)
+        else:
+            if A is None:      # fused forward did not materialise the operand: rebuild it for dW
+                A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
+                _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                          P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
+            gwcat = gemm_tn(A, g)                                # [(K+2)Hin, Hout] = A^T g
+            # grad_x: same aggregation over the transposed graph, then one GEMM
+            if _fused_ok(hin, hout):
+                wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
+                gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
+                _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                          P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D)
+            else:
+                U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
+                _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
+                          P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
+                gx = U @ wcat_t
         gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
         gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
         gwroot = gwcat[(K + 1) * hin:].t()
-        # grad_x: same aggregation over the transposed graph, then one GEMM
-        wcat_t = nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
-        if _fused_ok(hin, hout):
-            wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
-            gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
-            _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D)
-        else:
-            U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
-            _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                      P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
-            gx = U @ wcat_t
         # grad of the edge MLP's first layer
         wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
         if hin != hout:

@@ -149,6 +149,17 @@ int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const flo
 size_t qot_gemm_tn_workspace_floats(int KT);
 int qot_gemm_tn(const float* A, int lda, const float* G, int ldg, int64_t N, int KT, float* C,
                 float* workspace, qot_stream_t stream);
+/* NNConv backward, data and weight gradients from one gather (H == 64, D <= 4): grad_x = U @ WcatT
+ * (as qot_nnconv_fused transpose=1) and gwcat_t = per-block transposes of d/dWcat
+ * (gwcat_t[k*64+o][a] = dWcat[k*64+a][o]) computed as X^T U from the same LDS tile.  Replaces
+ * {qot_nnconv_fused(transpose=1), qot_nnconv_agg, qot_gemm_tn}.  x = the forward input rows.
+ * workspace: qot_nnconv_adjoint_dw_workspace_floats(D) floats. */
+size_t qot_nnconv_adjoint_dw_workspace_floats(int D);
+int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const float* x, int ld_x,
+                          const float* edge_attr, const float* w1, const float* b1,
+                          const int32_t* rowptr_t, const int32_t* col_t, const int32_t* eid_t,
+                          const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t,
+                          float* workspace, int64_t N, int H, int D, qot_stream_t stream);
 /* Fused form of {GA = g @ Wk^T ; qot_nnconv_bwd_edge} for H == 64, D <= 4: the GA tile is produced
  * by MFMA into LDS and consumed there.  b_perm: Wk^T in fragment order (csrc/nnconv_mfma.hip).
  * workspace: qot_nnconv_gradh_workspace_floats(D) floats.  gw1/gb1 are overwritten. */
