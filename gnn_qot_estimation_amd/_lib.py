@@ -35,7 +35,7 @@ SIGNATURES = {
     "qot_embed_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
-    "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
+    "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
                                  _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
     "qot_tconv_wedge_workspace_floats": (_sz, [_int, _int]),
@@ -67,6 +67,8 @@ SIGNATURES = {
     "qot_sgd_momentum": (_int, [_p, _p, _p, _i64, _f, _f, _p, _p]),
     "qot_colsum_workspace_floats": (_sz, [_int]),
     "qot_colsum": (_int, [_p, _int, _i64, _int, _p, _p, _p]),
+    "qot_rowsum_wide_workspace_floats": (_sz, [_i64]),
+    "qot_rowsum_wide": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),
 }

@@ -326,9 +326,50 @@ __global__ void colsum_final_kernel(const float* __restrict__ partials, int nblk
 }
 constexpr int kColsumBlocks = 1024;
 
+// out[c] = sum_b x[b*C + c] for WIDE rows (C up to millions, B rows): the sum over graphs of a
+// per-node gradient [B, n*W] (TransformerConv table mode).  grid = (C/4/256, S row slices);
+// slice partials [S, C] are summed by the second launch.  Coalesced 16-B accesses, 8 loads in flight.
+__global__ void rowsum_wide_kernel(const float* __restrict__ x, int64_t B, int64_t C, int S,
+                                   float* __restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;     // float4 column
+    if (t * 4 >= C) return;
+    const int64_t per = (B + S - 1) / S;
+    const int64_t b0 = blockIdx.y * per;
+    const int64_t b1 = (b0 + per < B) ? b0 + per : B;
+    float4 acc = f4zero();
+    int64_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld4(x + (b + u) * C + 4 * t);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+    }
+    for (; b < b1; ++b) acc = add4(acc, ld4(x + b * C + 4 * t));
+    st4(dst + (int64_t)blockIdx.y * C + 4 * t, acc);
+}
+constexpr int kRowsumSlices = 16;
+
 }  // namespace qot
 
 using namespace qot;
+
+extern "C" size_t qot_rowsum_wide_workspace_floats(int64_t C) { return (size_t)kRowsumSlices * (size_t)(C > 0 ? C : 0); }
+
+extern "C" int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out, float* workspace,
+                               qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B <= 0 || C <= 0 || !x || !out || !workspace) return QOT_ERR_BADARG;
+    if (C & 3) return QOT_ERR_UNSUPPORTED;
+    const int S = (B >= 4 * kRowsumSlices) ? kRowsumSlices : 1;
+    rowsum_wide_kernel<<<dim3(grid_for(C / 4, 256), S), 256, 0, stream>>>(x, B, C, S, S > 1 ? workspace : out);
+    QOT_LAUNCH_CHECK();
+    if (S > 1) {
+        rowsum_wide_kernel<<<dim3(grid_for(C / 4, 256), 1), 256, 0, stream>>>(workspace, S, C, 1, out);
+        QOT_LAUNCH_CHECK();
+    }
+    return QOT_OK;
+}
 
 extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                                 float momentum, int64_t* step_counter, qot_stream_t stream_) {

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     const float* __restrict__ v, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq, int ld_g,
-    float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
+    const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq,
+    float* __restrict__ gskip, int ld_g, float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
     int64_t N) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
         rc[c] *= rs;
     }
     st4(gq + i * ld_g + c0, make_float4(rc[0], rc[1], rc[2], rc[3]));
+    if (gskip) st4(gskip + i * ld_g + c0, gi);        // grad of the skip projection is grad_out itself
     if (sub == 0) {
         delta[i] = sada;
 #pragma unroll
@@ -309,8 +310,8 @@ extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, con
 extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v,
                                  int ld, const float* edge_attr, const float* w_edge,
                                  const float* stats, const int32_t* rowptr, const int32_t* col,
-                                 const int32_t* eid, const int32_t* rowmap, float* grad_q, int ld_g,
-                                 float* escr, float* delta, float* pds, float* pal, int64_t N, int H, int D,
+                                 const int32_t* eid, const int32_t* rowmap, float* grad_q, float* grad_skip,
+                                 int ld_g, float* escr, float* delta, float* pds, float* pal, int64_t N, int H, int D,
                                  qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
@@ -319,7 +320,7 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_bwd_dst_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, ld_g, escr,
+            grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, grad_skip, ld_g, escr,
             delta, pds, pal, N);
     }));
     QOT_LAUNCH_CHECK();

@@ -138,10 +138,9 @@ class TConvFn(torch.autograd.Function):
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
                   P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap),
-                  _off(gnode, 0), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
+                  _off(gnode, 0), _off(gnode, 3 * H), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
         _lib.call("qot_tconv_bwd_src", P(g), _off(qkvs, 0), H4, P(escr), P(delta), P(graph.rowptr_t),
                   P(graph.col_t), P(graph.pos_t), P(colf_t), _off(gnode, H), _off(gnode, 2 * H), H4, N, H)
-        gnode[:, 3 * H:] = g
         gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_tconv_wedge_workspace_floats(H, D), dtype=torch.float32, device=dev)
         _lib.call("qot_tconv_wedge_grad", _off(qkvs, 0), H4, P(rowmap), P(g), P(pds), P(pal), P(gwe), P(ws),
@@ -150,7 +149,9 @@ class TConvFn(torch.autograd.Function):
             gq = gnode
         else:
             B, n = maps[3]
-            gq = gnode.view(B, n * H4).sum(0).view(n, H4)     # table rows = sum over graphs
+            gq = torch.empty(n, H4, dtype=torch.float32, device=dev)       # table rows = sum over graphs
+            wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
+            _lib.call("qot_rowsum_wide", P(gnode), B, n * H4, P(gq), P(wsr))
             if n < qkvs.shape[0]:                              # table rows no node refers to
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
         return gq, None, gwe, None, None

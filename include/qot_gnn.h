@@ -97,12 +97,13 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
                   const float* edge_attr, const float* w_edge, const int32_t* rowptr,
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
                   float* stats, int64_t N, int H, int D, qot_stream_t stream);
-/* bwd, destination pass: grad_q[N,H] (ld_g), per-edge scratch escr[cap,2] = (alpha, dalpha),
+/* bwd, destination pass: grad_q[N,H] (ld_g), grad_skip[N,H] (= grad_out, same ld_g; may be NULL), per-edge scratch escr[cap,2] = (alpha, dalpha),
  * delta[N], pds[N,D] = sum_e ds_e ea_e, pal[N,D] = sum_e alpha_e ea_e. */
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,
                       const int32_t* rowptr, const int32_t* col, const int32_t* eid,
-                      const int32_t* rowmap, float* grad_q, int ld_g, float* escr, float* delta,
+                      const int32_t* rowmap, float* grad_q, float* grad_skip, int ld_g, float* escr,
+                      float* delta,
                       float* pds, float* pal, int64_t N, int H, int D, qot_stream_t stream);
 /* bwd, source pass: grad_k, grad_v [N,H] (ld_g).  qmap_t (table mode, else NULL): table row of
  * each out-edge's destination (node_ids[col_t]) for the q gather; grad_out/delta stay per node. */
@@ -238,6 +239,10 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
 int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                      float momentum, int64_t* step_counter, qot_stream_t stream);
 size_t qot_colsum_workspace_floats(int C);
+/* out[C] = sum over the B rows of x[B, C] for wide rows (sum over graphs of a per-node gradient,
+ * TransformerConv table mode); workspace: qot_rowsum_wide_workspace_floats(C) floats. */
+size_t qot_rowsum_wide_workspace_floats(int64_t C);
+int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out, float* workspace, qot_stream_t stream);
 int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace, qot_stream_t stream);
 
 /* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
