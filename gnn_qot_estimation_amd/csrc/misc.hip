@@ -287,15 +287,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // nesterov / weight decay -- topological_training/train.py:66): buf = mu*buf + g ; p -= lr*buf.
 // first_step: buf = g (torch initialises the momentum buffer with the first gradient).
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    int64_t n, float lr, float mu, const int64_t* __restrict__ step) {
+                                    int64_t n, float lr, float mu, int first) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const bool first = step[0] == 0;
     const float b = first ? g[t] : fmaf(mu, buf[t], g[t]);
     buf[t] = b;
     p[t] = fmaf(-lr, b, p[t]);
 }
-__global__ void bump_step_kernel(int64_t* step) { step[0] += 1; }
 
 // column sums of a row-major [N, C] matrix (bias gradients): per-block slices -> partials -> wave sums
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, int64_t N, int C,
@@ -326,6 +324,53 @@ __global__ void colsum_final_kernel(const float* __restrict__ partials, int nblk
 }
 constexpr int kColsumBlocks = 1024;
 
+// Small dense GEMM for the head MLP / embedding-table projection (a few MFLOP each; the library
+// GEMM spends 13-16 us per call on them): C[M,N] = op(A)[M,K] op(B)[K,N] (+ bias[N]), generic
+// element strides so every transpose variant (forward, grad_x, grad_W) is the same kernel.
+// 32x32 tile per 256-thread block, 2x2 per thread, K tiles of 32 through LDS.
+__global__ __launch_bounds__(256) void small_gemm_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                                         const float* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                         const float* __restrict__ bias, float* __restrict__ C,
+                                                         int ldc, int M, int N, int K, int kchunk) {
+    __shared__ float As[32][33];      // As[m][k]
+    __shared__ float Bs[32][33];      // Bs[k][n]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    float* Cz = C + (int64_t)blockIdx.z * M * ldc;          // split-K: one partial plane per z
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const bool a_k_fast = (sak == 1), b_n_fast = (sbn == 1);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        for (int t = threadIdx.x; t < 1024; t += 256) {
+            // consecutive threads walk whichever index is contiguous in memory
+            const int hi5 = t >> 5, lo5 = t & 31;
+            const int ar = a_k_fast ? hi5 : lo5, ac = a_k_fast ? lo5 : hi5;       // (m, k) within the tile
+            const int m = m0 + ar, k = k0 + ac;
+            As[ar][ac] = (m < M && k < kend) ? A[m * sam + k * sak] : 0.f;
+            const int br = b_n_fast ? hi5 : lo5, bc = b_n_fast ? lo5 : hi5;       // (k, n) within the tile
+            const int kk = k0 + br, n = n0 + bc;
+            Bs[br][bc] = (kk < kend && n < N) ? B[kk * sbk + n * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = As[ty][k], a1 = As[ty + 16][k];
+            const float b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < M && n < N) Cz[(int64_t)m * ldc + n] = acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
+        }
+}
+
 // out[c] = sum_b x[b*C + c] for WIDE rows (C up to millions, B rows): the sum over graphs of a
 // per-node gradient [B, n*W] (TransformerConv table mode).  grid = (C/4/256, S row slices);
 // slice partials [S, C] are summed by the second launch.  Coalesced 16-B accesses, 8 loads in flight.
@@ -354,6 +399,22 @@ constexpr int kRowsumSlices = 16;
 
 using namespace qot;
 
+extern "C" int qot_small_gemm(const float* A, int64_t stride_am, int64_t stride_ak, const float* B,
+                              int64_t stride_bk, int64_t stride_bn, const float* bias, float* C, int ldc, int M,
+                              int N, int K, int split_k, qot_stream_t stream) {
+    if (M < 0 || N < 0 || K < 0 || split_k < 1) return QOT_ERR_BADARG;
+    if (M == 0 || N == 0) return QOT_OK;
+    if (!A || !B || !C) return QOT_ERR_BADARG;
+    // split_k > 1: C must hold split_k planes of [M, ldc]; plane z gets the partial product of its
+    // K chunk (bias in plane 0); the caller sums the planes (fixed order)
+    int kchunk = ((K + split_k - 1) / split_k + 31) & ~31;
+    if (kchunk < 32) kchunk = 32;
+    small_gemm_kernel<<<dim3(grid_for(N, 32), grid_for(M, 32), split_k), 256, 0, (hipStream_t)stream>>>(
+        A, stride_am, stride_ak, B, stride_bk, stride_bn, bias, C, ldc, M, N, K, kchunk);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" size_t qot_rowsum_wide_workspace_floats(int64_t C) { return (size_t)kRowsumSlices * (size_t)(C > 0 ? C : 0); }
 
 extern "C" int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out, float* workspace,
@@ -372,15 +433,13 @@ extern "C" int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out,
 }
 
 extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
-                                float momentum, int64_t* step_counter, qot_stream_t stream_) {
+                                float momentum, int first_step, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n < 0 || !step_counter || (n > 0 && (!param || !grad || !momentum_buf))) return QOT_ERR_BADARG;
+    if (n < 0 || (n > 0 && (!param || !grad || !momentum_buf))) return QOT_ERR_BADARG;
     if (n > 0) {
-        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, lr, momentum, step_counter);
+        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, lr, momentum, first_step);
         QOT_LAUNCH_CHECK();
     }
-    bump_step_kernel<<<1, 1, 0, stream>>>(step_counter);
-    QOT_LAUNCH_CHECK();
     return QOT_OK;
 }
 

@@ -96,14 +96,15 @@ class FusedSGD:
     def __init__(self, flat: "FlatModel", lr: float, momentum: float = 0.0):
         self.flat, self.lr, self.momentum = flat, float(lr), float(momentum)
         self.buf = torch.zeros_like(flat.flat_param)
-        self.step_count = torch.zeros((), dtype=torch.long, device=flat.flat_param.device)
+        self.steps = 0          # host side; a captured graph bakes in "not the first step"
 
     def step(self):
         from . import _lib
         if not self.flat.flat_param.is_cuda:
             raise _lib.QotError("FusedSGD runs on the GPU only (use torch.optim.SGD on CPU)")
         _lib.call("qot_sgd_momentum", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
-                  _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, _lib.ptr(self.step_count))
+                  _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, int(self.steps == 0))
+        self.steps += 1
 
 
 def graph_range(num_graphs: int, rank: int, world: int):

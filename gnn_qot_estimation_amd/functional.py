@@ -84,6 +84,47 @@ class LinearFn(torch.autograd.Function):
         return gx, gw, colsum(g)
 
 
+def _small_gemm(a, b, bias, m, n, k, sam, sak, sbk, sbn):
+    # latency-bound problems: give every block at most two 32-deep K tiles (planes summed afterwards)
+    split = max(1, min(16, (k + 63) // 64)) if m * n <= 256 * 256 else 1
+    if split <= 1:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        _lib.call("qot_small_gemm", P(a), sam, sak, P(b), sbk, sbn, P(bias), P(out), n, m, n, k, 1)
+        return out
+    parts = torch.empty(split, m, n, dtype=torch.float32, device=a.device)
+    _lib.call("qot_small_gemm", P(a), sam, sak, P(b), sbk, sbn, P(bias), P(parts), n, m, n, k, split)
+    if (m * n) % 4:
+        return parts.sum(0)
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    ws = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(m * n), dtype=torch.float32, device=a.device)
+    _lib.call("qot_rowsum_wide", P(parts), split, m * n, P(out), P(ws))
+    return out
+
+
+class SmallLinearFn(torch.autograd.Function):
+    """``x @ W^T + b`` for the small dense layers (head MLP ``topological_training/models.py:33-38``,
+    embedding-table projection): one ``qot_small_gemm`` launch each for forward, grad_x, grad_W."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, weight, bias)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        m, k = x.shape
+        n = weight.shape[0]
+        ctx.save_for_backward(x, weight)
+        return _small_gemm(x, weight, bias, m, n, k, k, 1, 1, k)           # B(k,n) = W[n,k]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _f32c(g)
+        m, k = x.shape
+        n = weight.shape[0]
+        gx = _small_gemm(g, weight, None, m, k, n, n, 1, k, 1) if ctx.needs_input_grad[0] else None   # g @ W
+        gw = _small_gemm(g, x, None, n, k, m, 1, n, k, 1)                  # g^T @ x: A(i,r) = g[r,i]
+        return gx, gw, colsum(g) if m >= 64 else g.sum(0)
+
+
 # ------------------------------------------------------------------ TransformerConv (a2)
 class TConvFn(torch.autograd.Function):
     """Fused edge-softmax-aggregate of TransformerConv on packed projections.

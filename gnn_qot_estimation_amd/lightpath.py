@@ -64,4 +64,6 @@ class LightpathGNN(nn.Module):
         idx = self._lut_rows(data)
         lut_embedding = QF.RowsGatherFn.apply(x, to_i32(idx))
         lut_batch = batch.index_select(0, idx)
-        return self.mlp(lut_embedding), lut_batch
+        l0, act, drop, l3 = self.mlp[0], self.mlp[1], self.mlp[2], self.mlp[3]
+        h = QF.SmallLinearFn.apply(lut_embedding, l0.weight, l0.bias)       # head MLP (models.py:17-22,43)
+        return QF.SmallLinearFn.apply(drop(act(h)), l3.weight, l3.bias), lut_batch

@@ -64,7 +64,7 @@ class TransformerConv(nn.Module):
         """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
         ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows."""
         w, b = self.packed_weight()
-        t4 = F.linear(table, w, b)                    # [V, 4H]
+        t4 = QF.SmallLinearFn.apply(table, w, b)      # [V, 4H]
         return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps)
 
 

@@ -79,4 +79,11 @@ class TopologicalGNN(nn.Module):
             x = self._act(getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph), layer - 1, step)
         b32, ptr, B = batch_index_for(data, n)
         x = QF.PoolFn.apply(x, b32, ptr, B)
-        return self.mlp(x)
+        return self._head(x)
+
+    def _head(self, x):
+        """``self.mlp`` (Linear -> LeakyReLU -> Dropout -> Linear, models.py:33-38,63) with the two
+        dense layers on ``qot_small_gemm``; parameters stay in ``self.mlp`` (keys mlp.0 / mlp.3)."""
+        l0, act, drop, l3 = self.mlp[0], self.mlp[1], self.mlp[2], self.mlp[3]
+        h = QF.SmallLinearFn.apply(x, l0.weight, l0.bias)
+        return QF.SmallLinearFn.apply(drop(act(h)), l3.weight, l3.bias)

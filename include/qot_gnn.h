@@ -233,11 +233,17 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
                      qot_stream_t stream);
 
 /* ---- train-step envelope helpers (topological_training/train.py:109-116) ----------------
- * qot_sgd_momentum: torch.optim.SGD(lr, momentum) update over one flat buffer; step_counter is a
- * DEVICE int64 (0 on the first step: buf = grad), bumped by the call -- graph-replay safe.
+ * qot_sgd_momentum: torch.optim.SGD(lr, momentum) update over one flat buffer; first_step != 0
+ * initialises the momentum buffer with the gradient (torch semantics).
+ * qot_small_gemm: C[M,N] = op(A) op(B) (+bias) with element strides (head MLP, table projection:
+ * topological_training/models.py:33-38,63; a few MFLOP each).  split_k > 1: C holds split_k partial
+ * planes [M, ldc] (K chunks of ceil(K/split_k) rounded to 32), summed by the caller in a fixed order.
  * qot_colsum: out[C] = column sums of x[N, C] (bias gradients), deterministic two-stage. */
 int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
-                     float momentum, int64_t* step_counter, qot_stream_t stream);
+                     float momentum, int first_step, qot_stream_t stream);
+int qot_small_gemm(const float* A, int64_t stride_am, int64_t stride_ak, const float* B, int64_t stride_bk,
+                   int64_t stride_bn, const float* bias, float* C, int ldc, int M, int N, int K,
+                   int split_k, qot_stream_t stream);
 size_t qot_colsum_workspace_floats(int C);
 /* out[C] = sum over the B rows of x[B, C] for wide rows (sum over graphs of a per-node gradient,
  * TransformerConv table mode); workspace: qot_rowsum_wide_workspace_floats(C) floats. */
