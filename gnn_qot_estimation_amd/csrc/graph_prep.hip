@@ -177,6 +177,12 @@ __global__ void invdeg_kernel(const int32_t* __restrict__ rowptr, float* __restr
     invdeg[i] = 1.0f / (float)(d > 1 ? d : 1);
 }
 
+__global__ void i32_gather_kernel(const int32_t* __restrict__ map, const int32_t* __restrict__ idx,
+                                  int32_t* __restrict__ out, int64_t n) {
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = map[idx[i]];
+}
+
 __global__ void i64_to_i32_kernel(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)in[i];
@@ -258,6 +264,14 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
                                                       cur_out, pos_t, invdeg);
     QOT_LAUNCH_CHECK();
     csc_emit_kernel<<<grid_for(N, T), T, 0, stream>>>(N, rowptr_t, pos_t, row, eid, col_t, eid_t);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_i32_gather(const int32_t* map, const int32_t* idx, int32_t* out, int64_t n, qot_stream_t stream) {
+    if (n < 0 || (n > 0 && (!map || !idx || !out))) return QOT_ERR_BADARG;
+    if (n == 0) return QOT_OK;
+    i32_gather_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(map, idx, out, n);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

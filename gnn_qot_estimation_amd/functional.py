@@ -259,6 +259,28 @@ def nnconv_gradh_perm_index(k: int, device) -> torch.Tensor:
     return _PERM_CACHE[key]
 
 
+def nnconv_fused_indices(k: int, device):
+    """Gather indices into ``pflat = cat([nn.2.weight.flatten(), nn.2.bias, lin.weight.flatten()])``
+    (H = 64) that produce, with ONE gather each, the three fragment-ordered operands of the fused
+    NNConv kernels: Wcat (forward), WcatT (adjoint) and Wk^T (grad-h).  Replaces per-step
+    permute/reshape/cat chains (six small kernels) by host-side index composition, done once."""
+    key = ("fusedidx", k, str(device))
+    if key not in _PERM_CACHE:
+        h = 64
+        kk, a, o = torch.meshgrid(torch.arange(k), torch.arange(h), torch.arange(h), indexing="ij")
+        w2_off = (a * h + o) * k + kk                                   # Wcat[k*H + a, o] = W2[a*H+o, k]
+        a2, o2 = torch.meshgrid(torch.arange(h), torch.arange(h), indexing="ij")
+        b2_off = h * h * k + a2 * h + o2                                # block K: b2[a*H + o]
+        root_off = h * h * k + h * h + o2 * h + a2                      # block K+1: wroot[o, a]
+        wcat_idx = torch.cat([w2_off.reshape(k * h, h), b2_off, root_off], 0)          # [(K+2)H, H]
+        wcat_t_idx = wcat_idx.view(k + 2, h, h).transpose(1, 2).reshape((k + 2) * h, h)
+        fwd = wcat_idx.reshape(-1)[nnconv_perm_index((k + 2) * h, "cpu")]
+        adj = wcat_t_idx.reshape(-1)[nnconv_perm_index((k + 2) * h, "cpu")]
+        gh = wcat_idx[:k * h].reshape(-1)[nnconv_gradh_perm_index(k, "cpu")]
+        _PERM_CACHE[key] = tuple(t.contiguous().to(device) for t in (fwd, adj, gh))
+    return _PERM_CACHE[key]
+
+
 def _fused_ok(hin, hout):
     return hin == 64 and hout == 64
 
@@ -278,9 +300,10 @@ class NNConvFn(torch.autograd.Function):
             raise _lib.QotError("NNConv edge MLP must be Linear(D, 2D) -> ReLU -> Linear(2D, Hin*Hout)")
         if edge_attr.shape != (graph.num_edges_in, D):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
-        wcat = nnconv_wcat(w2, b2, wroot, hin, hout, K)
+        pflat = None
         if _fused_ok(hin, hout):
-            wp = wcat.reshape(-1)[nnconv_perm_index((K + 2) * hin, x.device)]
+            pflat = torch.cat([w2.reshape(-1), b2.reshape(-1), wroot.reshape(-1)])
+            wp = pflat[nnconv_fused_indices(K, x.device)[0]]
             out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
             _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D)
@@ -289,14 +312,14 @@ class NNConvFn(torch.autograd.Function):
             A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
             _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-            out = torch.addmm(bias, A, wcat)
-        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A)
+            out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, pflat)
         ctx.graph = graph
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, edge_attr, w1, b1, w2, b2, wroot, A = ctx.saved_tensors
+        x, edge_attr, w1, b1, w2, b2, wroot, A, pflat = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g)
         N, hin = x.shape
@@ -304,10 +327,11 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         gbias = colsum(g)
-        wcat_t = nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
-        if _fused_ok(hin, hout) and D <= 4 and not os.environ.get("QOT_SPLIT_NNCONV_BWD"):
+        fused_all = _fused_ok(hin, hout) and D <= 4 and pflat is not None and not os.environ.get("QOT_SPLIT_NNCONV_BWD")
+        wcat_t = None if fused_all else nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        if fused_all:
             # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U
-            wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
+            wp = pflat[nnconv_fused_indices(K, dev)[1]]
             gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
             gwt = torch.empty((K + 2) * hout, hin, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
@@ -335,17 +359,17 @@ class NNConvFn(torch.autograd.Function):
         gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
         gwroot = gwcat[(K + 1) * hin:].t()
         # grad of the edge MLP's first layer
-        wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
         if hin != hout:
             raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
-        if _fused_ok(hin, hout) and D <= 4:
-            bp = wk.reshape(-1)[nnconv_gradh_perm_index(K, dev)]
+        if _fused_ok(hin, hout) and D <= 4 and pflat is not None:
+            bp = pflat[nnconv_fused_indices(K, dev)[2]]
             gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
             gb1 = torch.empty(K, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_gradh_fused", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr),
                       P(graph.col), P(graph.eid), P(graph.invdeg), P(bp), P(gw1), P(gb1), P(ws), N, hin, D)
         else:
+            wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
             GA = g @ wk.t()                                      # [N, K*Hin]
             gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
             gb1 = torch.zeros(K, dtype=torch.float32, device=dev)

@@ -161,9 +161,12 @@ def table_maps_for(data, graph: GraphIndex, ids32: torch.Tensor):
     c = _cache(data)
     if c is not None and "tmaps" in c and c["tmaps"][0] == tag:
         return c["tmaps"][1]
-    colf = ids32.index_select(0, graph.col.long()[:max(graph.cap, 1)].clamp_(0, max(N - 1, 0)))
-    colf_t = ids32.index_select(0, graph.col_t.long()[:max(graph.cap, 1)].clamp_(0, max(N - 1, 0)))
-    res = (ids32, colf.contiguous(), colf_t.contiguous(), (N // n, int(n)))
+    E = graph.num_edges_in            # table mode is used without GAT self loops: every slot is live
+    colf = torch.empty(max(E, 1), dtype=torch.int32, device=ids32.device)
+    colf_t = torch.empty(max(E, 1), dtype=torch.int32, device=ids32.device)
+    _lib.call("qot_i32_gather", _lib.ptr(ids32), _lib.ptr(graph.col), _lib.ptr(colf), E)
+    _lib.call("qot_i32_gather", _lib.ptr(ids32), _lib.ptr(graph.col_t), _lib.ptr(colf_t), E)
+    res = (ids32, colf, colf_t, (N // n, int(n)))
     if c is not None:
         c["tmaps"] = (tag, res)
     return res

@@ -71,6 +71,9 @@ int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_
                   int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
                   int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg,
                   void* workspace, size_t workspace_bytes, qot_stream_t stream);
+/* out[i] = map[idx[i]] (int32): table row of every CSR / CSC slot's source / destination
+ * (node_ids[col], node_ids[col_t]) for TransformerConv's table mode.  idx values must be < len(map). */
+int qot_i32_gather(const int32_t* map, const int32_t* idx, int32_t* out, int64_t n, qot_stream_t stream);
 /* int64 -> int32 narrowing of node_ids / batch vectors */
 int qot_i64_to_i32(const int64_t* in, int32_t* out, int64_t n, qot_stream_t stream);
 /* ptr[B+1] from a sorted batch vector */
