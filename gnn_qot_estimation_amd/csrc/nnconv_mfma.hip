@@ -635,51 +635,61 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
                     for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
                 }
                 const int cnt = (end - base < 8) ? end - base : 8;
-                for (int u = 0; u < cnt; ++u) {
-                    const int64_t j = __shfl(myj, u, 8);
-                    float ee[D];
+                for (int u0 = 0; u0 < cnt; u0 += 4) {
+                    // four source rows in flight per destination group
+                    float4 xr0[4], xr1[4];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u, 8);
-                    const float4 x0 = ld4(x + j * ldx + c0), x1 = ld4(x + j * ldx + c0 + 4);
-                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t j = __shfl(myj, u0 + u, 8);
+                        const float* xp = x + (u0 + u < cnt ? j : 0) * ldx + c0;
+                        xr0[u] = ld4(xp); xr1[u] = ld4(xp + 4);
+                    }
 #pragma unroll
-                    for (int q = 0; q < KPL; ++q) {
-                        float pd[8];
+                    for (int u = 0; u < 4; ++u) {
+                        const bool live = u0 + u < cnt;
+                        float ee[D];
 #pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) {
-                            const int k = 8 * q + kk;
-                            float a = 0.f;
-                            if (k < K) {
+                        for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, 8);
+                        const float xv[8] = {xr0[u].x, xr0[u].y, xr0[u].z, xr0[u].w, xr1[u].x, xr1[u].y, xr1[u].z, xr1[u].w};
 #pragma unroll
-                                for (int t = 0; t < 8; ++t) a = fmaf(ga[k < K ? k : 0][t], xv[t], a);
+                        for (int q = 0; q < KPL; ++q) {
+                            float pd[8];
+#pragma unroll
+                            for (int kk = 0; kk < 8; ++kk) {
+                                const int k = 8 * q + kk;
+                                float a = 0.f;
+                                if (k < K) {
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) a = fmaf(ga[k < K ? k : 0][t], xv[t], a);
+                                }
+                                pd[kk] = a;
                             }
-                            pd[kk] = a;
+                            // transpose-reduce 8 values over 8 lanes: lane s ends with the total of value s
+                            float t4[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                const float keep = (sub & 4) ? pd[m + 4] : pd[m];
+                                const float send = (sub & 4) ? pd[m] : pd[m + 4];
+                                t4[m] = keep + __shfl_xor(send, 4);
+                            }
+                            float t2[2];
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                const float keep = (sub & 2) ? t4[m + 2] : t4[m];
+                                const float send = (sub & 2) ? t4[m] : t4[m + 2];
+                                t2[m] = keep + __shfl_xor(send, 2);
+                            }
+                            const float keep = (sub & 1) ? t2[1] : t2[0];
+                            const float send = (sub & 1) ? t2[0] : t2[1];
+                            const float tot = keep + __shfl_xor(send, 1);     // k = 8*q + sub
+                            float pre = brow[q];
+#pragma unroll
+                            for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);
+                            const float gh = (live && pre > 0.f && 8 * q + sub < K) ? tot * sc : 0.f;
+                            ab[q] += gh;
+#pragma unroll
+                            for (int d = 0; d < D; ++d) aw[q][d] = fmaf(gh, ee[d], aw[q][d]);
                         }
-                        // transpose-reduce 8 values over 8 lanes: lane s ends with the total of value s
-                        float t4[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const float keep = (sub & 4) ? pd[m + 4] : pd[m];
-                            const float send = (sub & 4) ? pd[m] : pd[m + 4];
-                            t4[m] = keep + __shfl_xor(send, 4);
-                        }
-                        float t2[2];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const float keep = (sub & 2) ? t4[m + 2] : t4[m];
-                            const float send = (sub & 2) ? t4[m] : t4[m + 2];
-                            t2[m] = keep + __shfl_xor(send, 2);
-                        }
-                        const float keep = (sub & 1) ? t2[1] : t2[0];
-                        const float send = (sub & 1) ? t2[0] : t2[1];
-                        const float tot = keep + __shfl_xor(send, 1);     // k = 8*q + sub
-                        float pre = brow[q];
-#pragma unroll
-                        for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);
-                        const float gh = (pre > 0.f && 8 * q + sub < K) ? tot * sc : 0.f;
-                        ab[q] += gh;
-#pragma unroll
-                        for (int d = 0; d < D; ++d) aw[q][d] = fmaf(gh, ee[d], aw[q][d]);
                     }
                 }
             }
