@@ -49,26 +49,53 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) aacc[d] = 0.f;
 
+    // In-edges in batches of TPR: lane `sub` of the group prefetches edge `sub`'s (source row,
+    // edge features) so the per-edge dependent chain (col -> rows) is paid once per batch, and
+    // four source rows are in flight per group.
     const int beg = rowptr[i], end = rowptr[i + 1];
-    for (int p = beg; p < end; ++p) {
-        const int64_t j = col[p];
-        const int64_t e = eid[p];
-        float4 kj = ld4(k + j * ld + c0);
-        float4 vj = ld4(v + j * ld + c0);
-        float ee[D];
+    constexpr int BT = (TPR < 16) ? TPR : 16;                 // edges prefetched per batch
+    for (int base = beg; base < end; base += BT) {
+        const int pme = base + sub;
+        int myj = 0;
+        float mye[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-        float s = group_sum<TPR>(dot4(qi, kj));
+        for (int d = 0; d < D; ++d) mye[d] = 0.f;
+        if (sub < BT && pme < end) {
+            myj = col[pme];
+            const int64_t e = eid[pme];
 #pragma unroll
-        for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
-        float mn = fmaxf(m, s);
-        float sc = __expf(m - mn);
-        float pe = __expf(s - mn);
-        l = fmaf(l, sc, pe);
-        acc = fma4(pe, vj, scale4(sc, acc));
+            for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+        }
+        const int cnt = (end - base < BT) ? end - base : BT;
+        for (int u0 = 0; u0 < cnt; u0 += 4) {
+            float4 kr[4], vr[4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) aacc[d] = fmaf(pe, ee[d], aacc[d] * sc);
-        m = mn;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = __shfl(myj, u0 + u, TPR);
+                const int64_t jr = (u0 + u < cnt) ? j : 0;
+                kr[u] = ld4(k + jr * ld + c0);
+                vr[u] = ld4(v + jr * ld + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u0 + u < cnt) {                           // group-uniform
+                    float ee[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
+                    float s = group_sum<TPR>(dot4(qi, kr[u]));
+#pragma unroll
+                    for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
+                    float mn = fmaxf(m, s);
+                    float sc = __expf(m - mn);
+                    float pe = __expf(s - mn);
+                    l = fmaf(l, sc, pe);
+                    acc = fma4(pe, vr[u], scale4(sc, acc));
+#pragma unroll
+                    for (int d = 0; d < D; ++d) aacc[d] = fmaf(pe, ee[d], aacc[d] * sc);
+                    m = mn;
+                }
+            }
+        }
     }
     const float denom = l + 1e-16f;
     const float inv = 1.0f / denom;
@@ -133,38 +160,63 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     float sada = 0.f;
 
     const int beg = rowptr[i], end = rowptr[i + 1];
-    for (int p = beg; p < end; ++p) {
-        const int64_t j = col[p];
-        const int64_t e = eid[p];
-        float4 kj = ld4(k + j * ld + c0);
-        float4 vj = ld4(v + j * ld + c0);
-        float ee[D];
+    constexpr int BT = (TPR < 16) ? TPR : 16;
+    for (int base = beg; base < end; base += BT) {
+        const int pme = base + sub;
+        int myj = 0;
+        float mye[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-        float s = dot4(qi, kj), da = dot4(gi, vj);
+        for (int d = 0; d < D; ++d) mye[d] = 0.f;
+        if (sub < BT && pme < end) {
+            myj = col[pme];
+            const int64_t e = eid[pme];
 #pragma unroll
-        for (int o = TPR / 2; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o);
-            da += __shfl_xor(da, o);
+            for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
         }
+        const int cnt = (end - base < BT) ? end - base : BT;
+        for (int u0 = 0; u0 < cnt; u0 += 4) {
+            float4 kr[4], vr[4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            s = fmaf(qe[d], ee[d], s);
-            da = fmaf(ge[d], ee[d], da);
-        }
-        const float a = __expf(s - m) * inv;
-        const float ada = a * da;
-        sada += ada;
-        a1 = fma4(ada, kj, a1);
-        a2 = fma4(a, kj, a2);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = __shfl(myj, u0 + u, TPR);
+                const int64_t jr = (u0 + u < cnt) ? j : 0;
+                kr[u] = ld4(k + jr * ld + c0);
+                vr[u] = ld4(v + jr * ld + c0);
+            }
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            p1[d] = fmaf(ada, ee[d], p1[d]);
-            p2[d] = fmaf(a, ee[d], p2[d]);
-        }
-        if (sub == 0) {
-            escr[2 * (int64_t)p] = a;
-            escr[2 * (int64_t)p + 1] = da;
+            for (int u = 0; u < 4; ++u) {
+                if (u0 + u < cnt) {
+                    const int p = base + u0 + u;
+                    float ee[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
+                    float s = dot4(qi, kr[u]), da = dot4(gi, vr[u]);
+#pragma unroll
+                    for (int o = TPR / 2; o > 0; o >>= 1) {
+                        s += __shfl_xor(s, o);
+                        da += __shfl_xor(da, o);
+                    }
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        s = fmaf(qe[d], ee[d], s);
+                        da = fmaf(ge[d], ee[d], da);
+                    }
+                    const float a = __expf(s - m) * inv;
+                    const float ada = a * da;
+                    sada += ada;
+                    a1 = fma4(ada, kr[u], a1);
+                    a2 = fma4(a, kr[u], a2);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        p1[d] = fmaf(ada, ee[d], p1[d]);
+                        p2[d] = fmaf(a, ee[d], p2[d]);
+                    }
+                    if (sub == 0) {
+                        escr[2 * (int64_t)p] = a;
+                        escr[2 * (int64_t)p + 1] = da;
+                    }
+                }
+            }
         }
     }
     float pd[D];
@@ -208,15 +260,38 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     const int c0 = 4 * sub;
     float4 ak = f4zero(), av = f4zero();
     const int beg = rowptr_t[j], end = rowptr_t[j + 1];
-    for (int t = beg; t < end; ++t) {
-        const int64_t i = col_t[t];
-        const int64_t p = pos_t[t];
-        const float a = escr[2 * p], da = escr[2 * p + 1];
-        const float ds = a * (da - delta[i]) * rs;
-        float4 gi = ld4(g + i * H + c0);
-        float4 qi = ld4(q + (qmap_t ? (int64_t)qmap_t[t] : i) * ld + c0);
-        av = fma4(a, gi, av);
-        ak = fma4(ds, qi, ak);
+    constexpr int BT = (TPR < 16) ? TPR : 16;
+    for (int base = beg; base < end; base += BT) {
+        const int tme = base + sub;
+        int myi = 0, myq = 0;
+        float mya = 0.f, myds = 0.f;
+        if (sub < BT && tme < end) {
+            myi = col_t[tme];
+            myq = qmap_t ? qmap_t[tme] : myi;
+            const int64_t p = pos_t[tme];
+            mya = escr[2 * p];
+            myds = mya * (escr[2 * p + 1] - delta[myi]) * rs;
+        }
+        const int cnt = (end - base < BT) ? end - base : BT;
+        for (int u0 = 0; u0 < cnt; u0 += 4) {
+            float4 gr[4], qr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = __shfl(myi, u0 + u, TPR);
+                const int64_t iq = __shfl(myq, u0 + u, TPR);
+                const bool live = u0 + u < cnt;
+                gr[u] = ld4(g + (live ? i : 0) * H + c0);
+                qr[u] = ld4(q + (live ? iq : 0) * ld + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = u0 + u < cnt;
+                const float a = live ? __shfl(mya, u0 + u, TPR) : 0.f;
+                const float ds = live ? __shfl(myds, u0 + u, TPR) : 0.f;
+                av = fma4(a, gr[u], av);
+                ak = fma4(ds, qr[u], ak);
+            }
+        }
     }
     st4(gk + j * ld_g + c0, ak);
     st4(gv + j * ld_g + c0, av);
