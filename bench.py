@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    ap.add_argument("--cpu-sample-graphs", type=int, default=16)
+    ap.add_argument("--cpu-sample-graphs", type=int, default=64)
     return ap.parse_args()
 
 
@@ -200,34 +200,56 @@ def kernel_table(model, batch):
 
 
 def cpu_baseline(sample_graphs):
-    """Oracle (PyG-style sparse restatement) train step on the host cores, bounded sample."""
+    """Oracle (PyG-style sparse restatement) train step on the host cores, bounded sample.
+
+    BASELINE.md's protocol says all cores; on this 256-core host that oversubscribes torch's
+    intra-op pool catastrophically (0.7-2.7 graphs/s at 256 threads vs >100 at 16), so the best of
+    a few thread counts is reported and ``cores`` is the count actually used."""
     from gnn_qot_estimation_amd import synthetic as S
     from oracle import sparse as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    m = O.TopologicalGNN(CFG["n"], CFG["H"], CFG["out"], CFG["D"], dropout_p=CFG["dropout"])
-    m.train()
-    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    ncpu = os.cpu_count() or 1
     b = S.topological_batch(CFG["cfg"], sample_graphs, n=CFG["n"], e=CFG["e"], edge_dim=CFG["D"])
     y = b.y.view(-1, CFG["out"])
+    best = None
+    tried = []
+    t_all = time.perf_counter()
+    for thr in sorted({t for t in (8, 16, 32, ncpu) if t <= ncpu}):
+        if thr > 64 and best is not None and time.perf_counter() - t_all > 20.0:
+            break
+        torch.set_num_threads(thr)
+        torch.manual_seed(0)
+        m = O.TopologicalGNN(CFG["n"], CFG["H"], CFG["out"], CFG["D"], dropout_p=CFG["dropout"])
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
 
-    def step():
-        opt.zero_grad()
-        loss = F.smooth_l1_loss(m(b), y)
-        loss.backward()
-        opt.step()
+        def step():
+            opt.zero_grad()
+            loss = F.smooth_l1_loss(m(b), y)
+            loss.backward()
+            opt.step()
 
-    step()                                   # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < 2 or (time.perf_counter() - t0 < 8.0 and iters < 20):      # ~10-30 s of CPU work in all
-        step()
-        iters += 1
-    dt = (time.perf_counter() - t0) / iters
-    return dict(value=sample_graphs / dt, unit="graphs/s", cores=cores, kind="port",
+        tw = time.perf_counter()
+        step()                                   # warm-up (allocator, thread pool)
+        tw = time.perf_counter() - tw
+        if best is not None and tw > 6 * best[0]:        # hopeless configuration (oversubscribed pool)
+            tried.append(f"{thr}t:{sample_graphs / tw:.1f}")
+            continue
+        t0 = time.perf_counter()
+        iters = 0
+        while iters < 2 or (time.perf_counter() - t0 < 3.0 and iters < 10):
+            step()
+            iters += 1
+        dt = (time.perf_counter() - t0) / iters
+        tried.append(f"{thr}t:{sample_graphs / dt:.1f}")
+        if best is None or dt < best[0]:
+            best = (dt, thr, iters)
+        if thr >= 64 and dt > 4 * best[0]:
+            break
+    dt, thr, iters = best
+    return dict(value=sample_graphs / dt, unit="graphs/s", cores=thr, kind="port",
                 sample=f"{iters} train steps of {sample_graphs} graphs (n=100,e=400,H=64; PyG-style [E,H*H] NNConv) "
-                       f"after 1 warm-up, {dt:.2f} s/step, torch {torch.__version__} CPU")
+                       f"after 1 warm-up, {dt:.2f} s/step at {thr} threads (best of {', '.join(tried)} graphs/s; "
+                       f"host has {ncpu} cores), torch {torch.__version__} CPU")
 
 
 def main():
