@@ -172,7 +172,7 @@ def kernel_table(model, batch):
 
     conv_in = N * H * 4 + E * D * 4 + csr + 4 * E + 4 * N        # x rows, edge features, CSR, eid, invdeg
     add("nnconv_fused_fwd", lambda: _lib.call("qot_nnconv_fused", P(x), H, P(ea), P(w1), P(b1), P(g.rowptr), P(g.col),
-                                              P(g.eid), P(g.invdeg), 0, P(wp), P(bias), P(out), N, H, D),
+                                              P(g.eid), P(g.invdeg), 0, P(wp), P(bias), P(out), N, H, D, 0, 0.0, 0.0, 0, None),
         conv_in + N * H * 4 + KT * H * 4, 2.0 * N * KT * H, "mfma")
     gwt = torch.empty(KT, H, device=dev)
     ws_a = torch.empty(lib.qot_nnconv_adjoint_dw_workspace_floats(D), device=dev)
@@ -185,7 +185,8 @@ def kernel_table(model, batch):
                                                 P(ws_h), N, H, D),
         conv_in + N * H * 4 + K * H * H * 4, 2.0 * N * H * K * H + 2.0 * E * K * H, "mfma")
     add("tconv_fwd", lambda: _lib.call("qot_tconv_fwd", off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H), off(qkvs, 3 * H),
-                                       4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), None, P(out), P(stats), N, H, D),
+                                       4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), None, P(out), P(stats), N, H, D,
+                                       0, 0.0, 0.0, 0, None),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
                                            4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,

@@ -35,14 +35,16 @@ SIGNATURES = {
     "qot_batch_ptr": (_int, [_p, _i64, _i64, _p, _p]),
     "qot_embed_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
-    "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
+    "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
+                             _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
                                  _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
     "qot_tconv_wedge_workspace_floats": (_sz, [_int, _int]),
     "qot_tconv_wedge_grad": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
-    "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int, _p]),
+    "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
+                                _int, _f, _f, _u64, _p, _p]),
     "qot_gemm_tn_workspace_floats": (_sz, [_int]),
     "qot_gemm_tn": (_int, [_p, _int, _p, _int, _i64, _int, _p, _p, _p]),
     "qot_nnconv_adjoint_dw_workspace_floats": (_sz, [_int]),

@@ -73,6 +73,62 @@ __device__ __forceinline__ float wave_sum_partials(const float* __restrict__ par
     return s;
 }
 
+// leaky_relu + dropout epilogue shared by qot_act_* and the conv kernels that fuse it.
+// One 64-bit hash per float4 of the [N, H] output (index = flat element index / 4), four 16-bit
+// draws out of it; keep = draw >= thr16.  qot_act_bwd regenerates the same mask from
+// (seed, *step, element), so forward kernels only have to use the same indexing.
+struct ActParams {
+    int enabled;            // 0: identity epilogue
+    float slope;            // leaky_relu negative slope
+    uint32_t thr16;         // round(p * 65536), 0 = no dropout
+    float keep_scale;       // 1 / (1 - p)
+    uint64_t seed;
+    const int64_t* step;    // device-side step counter (graph-replay safe), may be NULL when thr16 == 0
+};
+
+__device__ __forceinline__ uint64_t act_hash64(uint64_t seed, uint64_t step, uint64_t idx4) {
+    uint64_t z = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (idx4 * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float act_apply1(float v, const ActParams& a, uint64_t flat) {
+    if (!a.enabled) return v;
+    float y = v > 0.f ? v : a.slope * v;
+    if (a.thr16) {
+        const uint64_t z = act_hash64(a.seed, (uint64_t)a.step[0], flat >> 2);
+        const bool keep = ((uint32_t)(z >> (16 * (flat & 3))) & 0xFFFFu) >= a.thr16;
+        y = keep ? y * a.keep_scale : 0.f;
+    }
+    return y;
+}
+
+__device__ __forceinline__ float4 act_apply4(float4 v, const ActParams& a, uint64_t idx4) {
+    if (!a.enabled) return v;
+    float r[4] = {v.x, v.y, v.z, v.w};
+    uint64_t z = 0;
+    if (a.thr16) z = act_hash64(a.seed, (uint64_t)a.step[0], idx4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float y = r[c] > 0.f ? r[c] : a.slope * r[c];
+        if (a.thr16) y = (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= a.thr16) ? y * a.keep_scale : 0.f;
+        r[c] = y;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+inline ActParams make_act(int act, float slope, float p, uint64_t seed, const int64_t* step) {
+    ActParams a;
+    a.enabled = act; a.slope = slope; a.thr16 = 0; a.keep_scale = 1.0f; a.seed = seed; a.step = step;
+    if (act && p > 0.f && step) {
+        uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+        a.thr16 = thr > 65535u ? 65535u : thr;
+        a.keep_scale = 1.0f / (1.0f - p);
+    }
+    return a;
+}
+
 // XCD-aware block remap (bijective for any grid size).  Blocks are dealt round-robin over the 8
 // XCDs, each with a private L2; consecutive row blocks share gathered source rows (same graph),
 // so give every XCD a CONTIGUOUS range of row blocks.  Speed only -- any placement is correct.

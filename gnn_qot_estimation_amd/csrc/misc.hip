@@ -60,13 +60,6 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 
 // ----------------------------------------------------------------------------- activation
-__device__ __forceinline__ uint64_t hash64(uint64_t seed, uint64_t step, uint64_t idx4) {
-    uint64_t z = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (idx4 * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 template <bool BWD>
 __global__ void act_kernel(const float* __restrict__ a, const float* __restrict__ yref,
                            float* __restrict__ o, int64_t n4, float slope, uint32_t thr16,
@@ -78,7 +71,7 @@ __global__ void act_kernel(const float* __restrict__ a, const float* __restrict_
     float vr[4];
     if (BWD) { float4 r = ld4(yref + 4 * t); vr[0] = r.x; vr[1] = r.y; vr[2] = r.z; vr[3] = r.w; }
     uint64_t z = 0;
-    if (thr16) z = hash64(seed, (uint64_t)step_counter[0], (uint64_t)t);
+    if (thr16) z = act_hash64(seed, (uint64_t)step_counter[0], (uint64_t)t);
     float vo[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
     const float* __restrict__ b1, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, const float* __restrict__ Wp,
-    const float* __restrict__ bias, float* __restrict__ out, int64_t N) {
+    const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act) {
     constexpr int K = 2 * D;
     constexpr int KM = (K + 1) * 64;        // inner dimension held in LDS (blocks 0..K)
     constexpr int GM = KM / 16;             // float4 B groups per wave for the main part
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
             const int rr = kh * 8 + r;
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
             const int64_t i = tile0 + row;
-            if (i < N) out[i * 64 + colg] = v[r];
+            if (i < N) out[i * 64 + colg] = act_apply1(v[r], act, (uint64_t)(i * 64 + colg));
         }
     }
     QOT_STAMP(5)
@@ -753,33 +753,35 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
                                 const float* b1, const int32_t* rowptr, const int32_t* col,
                                 const int32_t* edge_ids, const float* invdeg, int transpose,
                                 const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
-                                qot_stream_t stream) {
+                                int act, float act_slope, float act_p, uint64_t act_seed,
+                                const int64_t* act_step, qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (H != 64) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
     if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
     int grid = grid_for(N, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    const ActParams ap = make_act(act, act_slope, act_p, act_seed, act_step);
     if (g_variant && D == 4 && !transpose) {
         if (g_variant == 3)
             nnconv_mfma64_kernel<4, false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
-                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else if (g_variant == 1)
             nnconv_mfma64_kernel<4, false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
-                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else
             nnconv_mfma64_kernel<4, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(
-                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         QOT_LAUNCH_CHECK();
         return QOT_OK;
     }
     QOT_DISPATCH_D(D, {
         if (transpose)
             nnconv_mfma64_kernel<kD, true><<<grid, 256, 0, (hipStream_t)stream>>>(
-                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else
             nnconv_mfma64_kernel<kD, false><<<grid, 256, 0, (hipStream_t)stream>>>(
-                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N);
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

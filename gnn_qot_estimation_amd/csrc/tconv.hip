@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     const float* __restrict__ skip, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap,
-    float* __restrict__ out, float* __restrict__ stats, int64_t N) {
+    float* __restrict__ out, float* __restrict__ stats, int64_t N, ActParams act) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
 #pragma unroll
         for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[c][d], aacc[d] * inv, oc[c]);
     float4 sk = ld4(skip + ri * ld + c0);
-    st4(out + i * H + c0, make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w));
+    st4(out + i * H + c0, act_apply4(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w), act,
+                                     (uint64_t)(i * H + c0) >> 2));
     if (sub == 0) {
         stats[2 * i] = (beg < end) ? m : 0.f;
         stats[2 * i + 1] = denom;
@@ -369,14 +370,16 @@ extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowma
 extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                              const float* edge_attr, const float* w_edge, const int32_t* rowptr,
                              const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
-                             float* stats, int64_t N, int H, int D, qot_stream_t stream) {
+                             float* stats, int64_t N, int H, int D, int act, float act_slope, float act_p,
+                             uint64_t act_seed, const int64_t* act_step, qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!q || !k || !v || !skip || !out || !stats || !w_edge || (ld & 3)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N);
+            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N,
+            make_act(act, act_slope, act_p, act_seed, act_step));
     }));
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -52,6 +52,25 @@ class EmbedFn(torch.autograd.Function):
         return gt, None
 
 
+def _act_args(act):
+    """(enabled, slope, p, seed, step_ptr) for the fused leaky_relu+dropout epilogue; ``act`` is
+    ``None`` or ``(slope, p, seed, step_counter_or_None)``."""
+    if act is None:
+        return 0, 0.0, 0.0, 0, None
+    slope, p, seed, step = act
+    return 1, float(slope), float(p if step is not None else 0.0), int(seed), P(step)
+
+
+def _act_backward(g, y, act):
+    """grad wrt the pre-activation given grad wrt ``y = dropout(leaky_relu(pre))``."""
+    slope, p, seed, step = act
+    g = _f32c(g)
+    gx = torch.empty_like(g)
+    _lib.call("qot_act_bwd", P(g), P(y), P(gx), g.numel(), float(slope), float(p if step is not None else 0.0),
+              int(seed), P(step))
+    return gx
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     """``x.sum(0)`` for a contiguous fp32 ``[N, C]`` CUDA matrix (bias gradients)."""
     n, c = x.shape
@@ -140,7 +159,7 @@ class TConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex, maps):
+    def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex, maps, act=None):
         require_cuda(qkvs, edge_attr, w_edge)
         qkvs, edge_attr, w_edge = _f32c(qkvs), _f32c(edge_attr), _f32c(w_edge)
         H4 = qkvs.shape[1]
@@ -156,16 +175,20 @@ class TConvFn(torch.autograd.Function):
         stats = torch.empty(N, 2, dtype=torch.float32, device=qkvs.device)
         _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
                   P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
-                  N, H, D)
-        ctx.save_for_backward(qkvs, edge_attr, w_edge, stats)
+                  N, H, D, *_act_args(act))
+        ctx.save_for_backward(qkvs, edge_attr, w_edge, stats, out if act is not None else None,
+                              act[3] if act is not None else None)
         ctx.graph, ctx.maps = graph, maps
+        ctx.act = None if act is None else (act[0], act[1], act[2])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        qkvs, edge_attr, w_edge, stats = ctx.saved_tensors
+        qkvs, edge_attr, w_edge, stats, y, act_step = ctx.saved_tensors
         graph, maps = ctx.graph, ctx.maps
         g = _f32c(g)
+        if ctx.act is not None:          # fused leaky_relu + dropout: back through it first
+            g = _act_backward(g, y, ctx.act + (act_step,))
         H4 = qkvs.shape[1]
         H = H4 // 4
         D = w_edge.shape[1]
@@ -195,7 +218,7 @@ class TConvFn(torch.autograd.Function):
             _lib.call("qot_rowsum_wide", P(gnode), B, n * H4, P(gq), P(wsr))
             if n < qkvs.shape[0]:                              # table rows no node refers to
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
-        return gq, None, gwe, None, None
+        return gq, None, gwe, None, None, None
 
 
 # ------------------------------------------------------------------ NNConv (a4)
@@ -289,7 +312,7 @@ class NNConvFn(torch.autograd.Function):
     """NNConv(aggr='mean') = aggregate-then-GEMM (see ``csrc/nnconv.hip``)."""
 
     @staticmethod
-    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex):
+    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex, act=None):
         require_cuda(x, edge_attr, w1, b1, w2, b2, wroot, bias)
         x, edge_attr = _f32c(x), _f32c(edge_attr)
         w1, b1, w2, b2, wroot, bias = (_f32c(t) for t in (w1, b1, w2, b2, wroot, bias))
@@ -306,22 +329,30 @@ class NNConvFn(torch.autograd.Function):
             wp = pflat[nnconv_fused_indices(K, x.device)[0]]
             out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
             _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                      P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D)
+                      P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
             A = None
         else:
             A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
             _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
             out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
-        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, pflat)
+            if act is not None:              # unfused width: separate activation kernel, same mask
+                pre = out
+                out = torch.empty_like(pre)
+                _lib.call("qot_act_fwd", P(pre), P(out), pre.numel(), *_act_args(act)[1:])
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, pflat, out if act is not None else None,
+                              act[3] if act is not None else None)
         ctx.graph = graph
+        ctx.act = None if act is None else (act[0], act[1], act[2])
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, edge_attr, w1, b1, w2, b2, wroot, A, pflat = ctx.saved_tensors
+        x, edge_attr, w1, b1, w2, b2, wroot, A, pflat, y, act_step = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g)
+        if ctx.act is not None:
+            g = _act_backward(g, y, ctx.act + (act_step,))
         N, hin = x.shape
         hout = wroot.shape[0]
         K, D = w1.shape
@@ -349,7 +380,8 @@ class NNConvFn(torch.autograd.Function):
                 wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
                 gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
                 _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                          P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D)
+                          P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D,
+                          0, 0.0, 0.0, 0, None)
             else:
                 U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
                 _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
@@ -375,7 +407,7 @@ class NNConvFn(torch.autograd.Function):
             gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
                       P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
-        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None
 
 
 # ------------------------------------------------------------------ leaky_relu + dropout (a3)

@@ -53,19 +53,21 @@ class TransformerConv(nn.Module):
         b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], 0)
         return w, b
 
-    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None):
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None):
+        """``act = (slope, p, seed, step_counter)`` fuses ``dropout(leaky_relu(.))`` into the kernel
+        epilogue (build extension; ``None`` = the plain PyG operator)."""
         if graph is None:
             graph = build_graph_index(edge_index, x.shape[0])
         w, b = self.packed_weight()
         qkvs = QF.LinearFn.apply(x, w, b)             # one MFMA GEMM for q|k|v|skip
-        return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph, None)
+        return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph, None, act)
 
-    def forward_table(self, table, edge_attr, graph: GraphIndex, maps):
+    def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None):
         """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
         ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows."""
         w, b = self.packed_weight()
         t4 = QF.SmallLinearFn.apply(table, w, b)      # [V, 4H]
-        return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps)
+        return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps, act)
 
 
 class NNConv(nn.Module):
@@ -98,11 +100,11 @@ class NNConv(nn.Module):
                                       "topological_training/models.py:20-24")
         return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
 
-    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None):
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None):
         if graph is None:
             graph = build_graph_index(edge_index, x.shape[0])
         w1, b1, w2, b2 = self._edge_mlp()
-        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph)
+        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph, act)
 
 
 class GATConv(nn.Module):

@@ -45,13 +45,14 @@ class TopologicalGNN(nn.Module):
         self.register_buffer("_qot_step", torch.zeros((), dtype=torch.long), persistent=False)
         self._qot_seed = None
 
-    def _act(self, x, site: int, step):
-        """leaky_relu(0.01) + Dropout(p) of models.py:54-55 / 58-59 as one kernel."""
+    def _act(self, site: int, step):
+        """``(slope, p, seed, step)`` of the leaky_relu(0.01) + Dropout(p) that follows conv
+        ``site`` (models.py:54-55 / 58-59); the conv kernels apply it in their epilogue."""
         p = self.dropout.p if self.training else 0.0
         if self._qot_seed is None:
             self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         seed = (self._qot_seed + 0x9E3779B97F4A7C15 * (site + 1)) & 0xFFFFFFFFFFFFFFFF
-        return QF.ActFn.apply(x, 0.01, p, seed, step if p > 0.0 else None)
+        return (0.01, p, seed, step if p > 0.0 else None)
 
     def forward(self, data):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
@@ -71,12 +72,11 @@ class TopologicalGNN(nn.Module):
             self._qot_step.add_(1)
             step = self._qot_step.clone()   # this forward's draw; backward re-reads the clone
         if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
-            x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps)
+            x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step))
         else:
-            x = self.conv1(x, edge_index, edge_attr, graph=graph)
-        x = self._act(x, 0, step)
+            x = self.conv1(x, edge_index, edge_attr, graph=graph, act=self._act(0, step))
         for layer in range(2, self.num_layers + 1):
-            x = self._act(getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph), layer - 1, step)
+            x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=self._act(layer - 1, step))
         b32, ptr, B = batch_index_for(data, n)
         x = QF.PoolFn.apply(x, b32, ptr, B)
         return self._head(x)

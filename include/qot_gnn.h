@@ -91,6 +91,9 @@ int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, 
  * fwd: out_i = sum_e softmax_e(<q_i, k_j + We ea_e>/sqrt(H)) (v_j + We ea_e) + skip_i
  * stats[N,2] = (max logit, denominator incl. 1e-16) saved for backward.
  * edge_attr is in ORIGINAL edge order ([E,D]); the kernels index it through eid.
+ * act != 0 fuses dropout(leaky_relu(out, act_slope), act_p) into the epilogue with the mask of
+ * qot_act_fwd/qot_act_bwd (same seed / step counter / element indexing), so the backward is
+ * qot_act_bwd(grad, out) followed by the conv backward.
  * Table mode (rowmap != NULL): q/k/v/skip are rows of a PROJECTED EMBEDDING TABLE [V, 4H]
  * ((emb W^T + b)[node_ids] == (emb[node_ids]) W^T + b, topological_training/models.py:51-53);
  * rowmap[i] = table row of node i and `col` must then hold the table row of each in-edge's source
@@ -99,7 +102,8 @@ int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, 
 int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                   const float* edge_attr, const float* w_edge, const int32_t* rowptr,
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
-                  float* stats, int64_t N, int H, int D, qot_stream_t stream);
+                  float* stats, int64_t N, int H, int D, int act, float act_slope, float act_p,
+                  uint64_t act_seed, const int64_t* act_step, qot_stream_t stream);
 /* bwd, destination pass: grad_q[N,H] (ld_g), grad_skip[N,H] (= grad_out, same ld_g; may be NULL), per-edge scratch escr[cap,2] = (alpha, dalpha),
  * delta[N], pds[N,D] = sum_e ds_e ea_e, pal[N,D] = sum_e alpha_e ea_e. */
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
@@ -145,6 +149,7 @@ int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const flo
                      const float* b1, const int32_t* rowptr, const int32_t* col,
                      const int32_t* edge_ids, const float* invdeg, int transpose,
                      const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                     int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
                      qot_stream_t stream);
 /* C[KT,64] = A[N,KT]^T @ G[N,64] (fp32 MFMA, operands streamed from HBM in fragment order,
  * deterministic slab reduction).  Weight-gradient GEMM of NNConv (gWcat = A^T g) -- the shape

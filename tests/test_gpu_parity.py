@@ -272,3 +272,32 @@ def test_table_mode_is_used_and_table_larger_than_graph(cuda_device):
     torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
     _grad_compare(ref, hip)
     assert float(hip.node_embeddings.weight.grad[14:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H", [64, 32])
+def test_fused_activation_epilogue_equals_separate_kernel(cuda_device, H):
+    """conv(..., act=(slope, p, seed, step)) must equal ActFn(conv(...)) bit for bit (same mask:
+    same seed / step / element indexing), forward and input gradient, with dropout ON."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import functional as QF, synthetic as S
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    torch.manual_seed(0)
+    b = S.topological_batch(2, 6, n=50, e=160).to(cuda_device)
+    N = b.num_nodes
+    g = build_graph_index(b.edge_index, N)
+    step = torch.tensor(5, device=cuda_device)
+    act = (0.01, 0.5, 987654321, step)
+    tc = q.TransformerConv(H, H, edge_dim=4).to(cuda_device)
+    edge_nn = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, H * H))
+    nc = q.NNConv(H, H, nn=edge_nn, aggr="mean").to(cuda_device)
+    for conv in (tc, nc):
+        x1 = torch.randn(N, H, device=cuda_device, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        y_fused = conv(x1, b.edge_index, b.edge_attr, graph=g, act=act)
+        y_sep = QF.ActFn.apply(conv(x2, b.edge_index, b.edge_attr, graph=g), *act)
+        assert torch.equal(y_fused, y_sep)
+        assert 0.4 < float((y_fused == 0).float().mean()) < 0.6
+        w = torch.randn_like(y_fused)
+        (y_fused * w).sum().backward()
+        (y_sep * w).sum().backward()
+        assert torch.equal(x1.grad, x2.grad)

@@ -17,7 +17,7 @@ bias = torch.randn(H, device=dev); out = torch.empty(N, H, device=dev)
 lib = _lib.load(); lib.qot_debug_set_variant.argtypes = [ctypes.c_int]
 def run():
     _lib.call("qot_nnconv_fused", P(x), H, P(b.edge_attr), P(w1), P(b1), P(g.rowptr), P(g.col), P(g.eid),
-              P(g.invdeg), 0, P(wp), P(bias), P(out), N, H, D)
+              P(g.invdeg), 0, P(wp), P(bias), P(out), N, H, D, 0, 0.0, 0.0, 0, None)
 def t(iters=20):
     st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); st.record()
