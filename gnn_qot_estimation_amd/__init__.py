@@ -8,8 +8,9 @@ underneath is replaced by hand-written gfx950 HIP kernels in ``libqot_gnn.so``
 """
 from .batch import Batch, Data, shard_graphs
 from .lightpath import LightpathGNN
+from .loader import GraphLoader, PackedGraphs
 from .nn import BatchNorm, GATConv, NNConv, TransformerConv, global_mean_pool
 from .topological import TopologicalGNN
 
 __all__ = ["Batch", "Data", "shard_graphs", "TopologicalGNN", "LightpathGNN", "TransformerConv", "NNConv",
-           "GATConv", "BatchNorm", "global_mean_pool"]
+           "GATConv", "BatchNorm", "global_mean_pool", "GraphLoader", "PackedGraphs"]
