@@ -1,0 +1,194 @@
+// Fused read-out head of TopologicalGNN:  global_mean_pool -> Linear(H,H) -> LeakyReLU(0.01) ->
+// Dropout(p) -> Linear(H,O)   (topological_training/models.py:33-38,61-63) and its backward.
+// As separate launches this tail was ~25 kernels / ~145 us per step at B = 1024 (nine small GEMMs,
+// split-K sums, pool forward/backward, bias column sums, elementwise); the arithmetic is a few
+// MFLOP.  Forward: one workgroup per graph.  Backward: a fixed number of workgroups, each walks its
+// graphs keeping the partial weight gradients in registers; partials are summed in a fixed order.
+#include "common.hpp"
+
+namespace qot {
+
+constexpr int kHeadBwdBlocks = 256;
+
+// dynamic LDS: p[H] | h[H]
+template <int H>
+__global__ __launch_bounds__(256) void head_fwd_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ ptr, const float* __restrict__ w0,
+    const float* __restrict__ b0, const float* __restrict__ w3, const float* __restrict__ b3,
+    float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ out, int O, ActParams act) {
+    __shared__ float4 red[256];
+    __shared__ float p[H];
+    __shared__ float h[H];
+    constexpr int TPR = H / 4, RPB = 256 / TPR;
+    const int sub = threadIdx.x % TPR, slot = threadIdx.x / TPR;
+    const int64_t b = blockIdx.x;
+    const int beg = ptr[b], end = ptr[b + 1];
+    float4 acc = f4zero();
+    if (slot < RPB)
+        for (int64_t r = beg + slot; r < end; r += RPB) acc = add4(acc, ld4(x + r * H + 4 * sub));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < TPR) {
+        float4 s = red[threadIdx.x];
+        for (int k = 1; k < RPB; ++k) s = add4(s, red[k * TPR + threadIdx.x]);
+        const int cnt = end - beg;
+        s = scale4(1.0f / (float)(cnt > 1 ? cnt : 1), s);
+        p[4 * threadIdx.x] = s.x; p[4 * threadIdx.x + 1] = s.y; p[4 * threadIdx.x + 2] = s.z; p[4 * threadIdx.x + 3] = s.w;
+        st4(pooled + b * H + 4 * threadIdx.x, s);
+    }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int o = threadIdx.x;
+        float v = b0[o];
+#pragma unroll 8
+        for (int a = 0; a < H; ++a) v = fmaf(w0[o * H + a], p[a], v);
+        v = act_apply1(v, act, (uint64_t)(b * H + o));          // LeakyReLU + Dropout
+        h[o] = v;
+        hidden[b * H + o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < O) {
+        const int o = threadIdx.x;
+        float v = b3[o];
+        for (int a = 0; a < H; ++a) v = fmaf(w3[o * H + a], h[a], v);
+        out[b * O + o] = v;
+    }
+}
+
+// Backward.  Per graph: gh = (W3^T gout) * act'(hidden) ; gp = W0^T gh ; grad_x rows = gp / count.
+// Weight-gradient partials per block: gW0[H,H] (thread t owns rows (t>>2)..., see below), gb0[H],
+// gW3[O,H], gb3[O].  Layout of one partial: [H*H | H | O*H | O].
+template <int H>
+__global__ __launch_bounds__(256) void head_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ pooled, const float* __restrict__ hidden,
+    const int32_t* __restrict__ ptr, const float* __restrict__ w0, const float* __restrict__ w3,
+    float* __restrict__ gx, float* __restrict__ partials, int64_t B, int O, ActParams act) {
+    constexpr int PER = H * H / 256;                  // gW0 elements per thread (16 at H = 64)
+    __shared__ float gh[H];
+    __shared__ float gp[H];
+    __shared__ float pp[H];
+    __shared__ float go[8];
+    float aw0[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) aw0[e] = 0.f;
+    float ab0 = 0.f, aw3[8], ab3 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw3[e] = 0.f;
+    const int t = threadIdx.x;
+    // gW0 element e of thread t: row o = (t*PER + e) / H, col a = (t*PER + e) % H
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        if (t < O) go[t] = gout[b * O + t];
+        if (t < H) pp[t] = pooled[b * H + t];
+        __syncthreads();
+        if (t < H) {
+            float v = 0.f;
+            for (int o = 0; o < O; ++o) v = fmaf(w3[o * H + t], go[o], v);
+            const float hv = hidden[b * H + t];
+            // d/dpre of dropout(leaky_relu(pre)): hidden == 0 <=> dropped (or pre == 0)
+            float d = 0.f;
+            if (act.thr16) {
+                const uint64_t z = act_hash64(act.seed, (uint64_t)act.step[0], (uint64_t)(b * H + t) >> 2);
+                const bool keep = ((uint32_t)(z >> (16 * ((b * H + t) & 3))) & 0xFFFFu) >= act.thr16;
+                d = keep ? act.keep_scale : 0.f;
+            } else {
+                d = 1.0f;
+            }
+            d *= (hv > 0.f) ? 1.0f : act.slope;
+            gh[t] = v * d;
+            ab0 += v * d;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) aw3[o] = fmaf(go[o], hv, aw3[o]);     // gW3[o, t]
+        }
+        if (t < O) ab3 += go[t];
+        __syncthreads();
+        if (t < H) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int o = 0; o < H; ++o) v = fmaf(w0[o * H + t], gh[o], v);
+            gp[t] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = t * PER + e;
+            aw0[e] = fmaf(gh[idx / H], pp[idx % H], aw0[e]);
+        }
+        __syncthreads();
+        // pool backward: every node row of the graph gets gp / count
+        const int beg = ptr[b], end = ptr[b + 1];
+        const float inv = 1.0f / (float)((end - beg) > 1 ? (end - beg) : 1);
+        constexpr int TPR = H / 4, RPB = 256 / TPR;
+        const int sub = t % TPR, slot = t / TPR;
+        if (slot < RPB) {
+            const float4 v = make_float4(gp[4 * sub] * inv, gp[4 * sub + 1] * inv, gp[4 * sub + 2] * inv, gp[4 * sub + 3] * inv);
+            for (int64_t r = beg + slot; r < end; r += RPB) st4(gx + r * H + 4 * sub, v);
+        }
+        __syncthreads();
+    }
+    float* part = partials + (int64_t)blockIdx.x * (H * H + H + O * H + O);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) part[t * PER + e] = aw0[e];
+    if (t < H) {
+        part[H * H + t] = ab0;
+        for (int o = 0; o < O; ++o) part[H * H + H + o * H + t] = aw3[o];
+    }
+    if (t < O) part[H * H + H + O * H + t] = ab3;
+}
+
+__global__ void head_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const float s = wave_sum_partials(partials, nblk, n, t);
+    if ((threadIdx.x & 63) == 0) out[t] = s;
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+#define QOT_HEAD_H(H, ...)                                            \
+    switch (H) {                                                      \
+        case 16:  { constexpr int kH = 16;  __VA_ARGS__; } break;     \
+        case 32:  { constexpr int kH = 32;  __VA_ARGS__; } break;     \
+        case 64:  { constexpr int kH = 64;  __VA_ARGS__; } break;     \
+        case 128: { constexpr int kH = 128; __VA_ARGS__; } break;     \
+        default: return QOT_ERR_UNSUPPORTED;                          \
+    }
+
+extern "C" int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0,
+                            const float* w3, const float* b3, float* pooled, float* hidden, float* out,
+                            int64_t B, int H, int O, float slope, float p, uint64_t seed,
+                            const int64_t* step_counter, qot_stream_t stream) {
+    if (B < 0 || O <= 0 || O > 8) return (O > 8) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
+    if (B == 0) return QOT_OK;
+    if (!x || !ptr || !w0 || !b0 || !w3 || !b3 || !pooled || !hidden || !out) return QOT_ERR_BADARG;
+    const ActParams ap = make_act(1, slope, p, seed, step_counter);
+    QOT_HEAD_H(H, head_fwd_kernel<kH><<<(int)B, 256, 0, (hipStream_t)stream>>>(x, ptr, w0, b0, w3, b3, pooled, hidden,
+                                                                              out, O, ap));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" size_t qot_head_bwd_workspace_floats(int H, int O) {
+    return (size_t)kHeadBwdBlocks * (size_t)(H * H + H + O * H + O);
+}
+
+// grads: [gW0 (H*H) | gb0 (H) | gW3 (O*H) | gb3 (O)] contiguous in `grads`
+extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
+                            const float* w0, const float* w3, float* grad_x, float* grads, float* workspace,
+                            int64_t B, int H, int O, float slope, float p, uint64_t seed,
+                            const int64_t* step_counter, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B <= 0 || O <= 0) return QOT_ERR_BADARG;
+    if (O > 8) return QOT_ERR_UNSUPPORTED;
+    if (!grad_out || !pooled || !hidden || !ptr || !w0 || !w3 || !grad_x || !grads || !workspace) return QOT_ERR_BADARG;
+    const ActParams ap = make_act(1, slope, p, seed, step_counter);
+    int blocks = kHeadBwdBlocks;
+    if (B < blocks) blocks = (int)B;
+    QOT_HEAD_H(H, head_bwd_kernel<kH><<<blocks, 256, 0, stream>>>(grad_out, pooled, hidden, ptr, w0, w3, grad_x,
+                                                                  workspace, B, O, ap));
+    QOT_LAUNCH_CHECK();
+    const int n = H * H + H + O * H + O;
+    head_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, blocks, n, grads);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

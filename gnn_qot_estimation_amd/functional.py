@@ -457,6 +457,47 @@ class PoolFn(torch.autograd.Function):
         return gx, None, None, None
 
 
+# ------------------------------------------------------------------ fused read-out head (a5 + a6)
+class HeadFn(torch.autograd.Function):
+    """``mlp(global_mean_pool(x, batch))`` of ``topological_training/models.py:61-63`` in one kernel
+    each way: pool -> Linear -> LeakyReLU -> Dropout -> Linear, and the whole backward (incl. pool
+    backward and all four parameter gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, ptr32, w0, b0, w3, b3, B, act):
+        require_cuda(x, w0, b0, w3, b3)
+        x, w0, b0, w3, b3 = (_f32c(t) for t in (x, w0, b0, w3, b3))
+        N, H = x.shape
+        O = w3.shape[0]
+        slope, p, seed, step = act
+        dev = x.device
+        pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
+        hidden = torch.empty(B, H, dtype=torch.float32, device=dev)
+        out = torch.empty(B, O, dtype=torch.float32, device=dev)
+        _lib.call("qot_head_fwd", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H, O,
+                  float(slope), float(p if step is not None else 0.0), int(seed), P(step))
+        ctx.save_for_backward(ptr32, w0, w3, pooled, hidden, step)
+        ctx.cfg = (N, H, O, B, float(slope), float(p if step is not None else 0.0), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ptr32, w0, w3, pooled, hidden, step = ctx.saved_tensors
+        N, H, O, B, slope, p, seed = ctx.cfg
+        g = _f32c(g)
+        dev = g.device
+        gx = torch.empty(N, H, dtype=torch.float32, device=dev)
+        grads = torch.empty(H * H + H + O * H + O, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_head_bwd_workspace_floats(H, O), dtype=torch.float32, device=dev)
+        _lib.call("qot_head_bwd", P(g), P(pooled), P(hidden), P(ptr32), P(w0), P(w3), P(gx), P(grads), P(ws), B, H, O,
+                  slope, p, seed, P(step))
+        gw0 = grads[:H * H].view(H, H)
+        gb0 = grads[H * H:H * H + H]
+        gw3 = grads[H * H + H:H * H + H + O * H].view(O, H)
+        gb3 = grads[H * H + H + O * H:]
+        return gx, None, gw0, gb0, gw3, gb3, None, None
+
+
 # ------------------------------------------------------------------ GATConv (a7)
 class GatFn(torch.autograd.Function):
     """Fused GAT edge softmax + aggregation (+bias).  ``graph`` carries the self loops."""

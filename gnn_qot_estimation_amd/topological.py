@@ -78,6 +78,15 @@ class TopologicalGNN(nn.Module):
         for layer in range(2, self.num_layers + 1):
             x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=self._act(layer - 1, step))
         b32, ptr, B = batch_index_for(data, n)
+        l0, l3 = self.mlp[0], self.mlp[3]
+        if x.shape[1] in (16, 32, 64, 128) and l3.out_features <= 8 and l0.out_features == x.shape[1]:
+            # pool + head MLP (models.py:61-63) fused: one kernel forward, one backward
+            p = self.mlp[2].p if self.training else 0.0
+            if self._qot_seed is None:
+                self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            seed = (self._qot_seed + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
+            act = (self.mlp[1].negative_slope, p, seed, step if p > 0.0 else None)
+            return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act)
         x = QF.PoolFn.apply(x, b32, ptr, B)
         return self._head(x)
 

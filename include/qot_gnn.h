@@ -259,6 +259,19 @@ size_t qot_rowsum_wide_workspace_floats(int64_t C);
 int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out, float* workspace, qot_stream_t stream);
 int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace, qot_stream_t stream);
 
+/* ---- fused read-out head: global_mean_pool -> Linear(H,H) -> LeakyReLU -> Dropout -> Linear(H,O)
+ * (topological_training/models.py:33-38,61-63).  fwd saves pooled[B,H] and hidden[B,H] (post dropout).
+ * bwd: grad_x[N,H] (pool backward included) and grads = [gW0 | gb0 | gW3 | gb3] contiguous
+ * (deterministic partial sums; workspace qot_head_bwd_workspace_floats(H, O) floats).  O <= 8. */
+int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
+                 const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
+                 float slope, float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream);
+size_t qot_head_bwd_workspace_floats(int H, int O);
+int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
+                 const float* w0, const float* w3, float* grad_x, float* grads, float* workspace, int64_t B,
+                 int H, int O, float slope, float p, uint64_t seed, const int64_t* step_counter,
+                 qot_stream_t stream);
+
 /* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
 int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,
                     qot_stream_t stream);
