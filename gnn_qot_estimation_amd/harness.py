@@ -1,0 +1,288 @@
+"""Train / evaluate loops with the behaviour of the reference scripts, driving the HIP models.
+
+Counterpart of ``topological_training/train.py``, ``lightpath_training/train.py`` and the two
+``test.py``.  What is kept from the reference: the 70/15/15 split without
+shuffling (train.py:29-36), one 10 % chunk of the training range per epoch (train.py:79-90),
+SGD(lr=0.1, momentum=0.9) with StepLR(step_size=10, gamma=0.5) (train.py:66-67), SmoothL1 loss
+(train.py:69), sample-weighted epoch loss and uniform-average R2 (train.py:119-131), early stopping on
+validation R2 with patience 10 and a best-model file (train.py:168-178), the checkpoint dictionary
+(train.py:196-209), LUT target selection and batch skipping for LightpathGNN
+(lightpath_training/train.py:112-135), min-max descaling and per-output R2 / MSE at test time
+(topological_training/test.py:88-108).
+
+What is different, because the device is an MI355X and not a laptop CPU: batches come from
+``GraphLoader`` (pinned, prefetched), nothing in the batch loop reads a value back to the host -- the
+loss sum and the R2 sufficient statistics accumulate on the device and are fetched once per epoch --
+and the optimizer is one fused kernel over the flat parameter buffer.  With ``torch.distributed``
+initialised every rank takes its share of each batch range and the statistics are summed over ranks.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .dp import FlatModel, FusedSGD, graph_range
+from .loader import GraphLoader
+
+# data constants of the reference's label scaling (constants.py:8-12), used at test.py:95-99
+TARGET_RANGES = {
+    "osnr": {"min": 12.47, "max": 33.49},
+    "snr": {"min": 8.96, "max": 29.98},
+    "ber": {"min": 1.70e-12, "max": 1.98e-2},
+}
+
+
+def split_ranges(total: int) -> Tuple[range, range, range]:
+    """70 / 15 / 15 split in dataset order (train.py:29-36)."""
+    tr = int(total * 0.7)
+    va = int(total * 0.15)
+    return range(0, tr), range(tr, tr + va), range(tr + va, total)
+
+
+def epoch_chunk(epoch: int, train_len: int, fraction: float = 0.10) -> range:
+    """The slice of the training range epoch ``epoch`` sees (train.py:79-90)."""
+    num_chunks = int(1 / fraction)
+    size = train_len // num_chunks
+    start = (epoch % num_chunks) * size
+    return range(start, min(start + size, train_len))
+
+
+def step_lr(base_lr: float, epoch: int, step_size: int = 10, gamma: float = 0.5) -> float:
+    """Learning rate in effect during ``epoch`` under StepLR stepped once per epoch (train.py:67,181)."""
+    return base_lr * gamma ** (epoch // step_size)
+
+
+class RegressionStats:
+    """Streaming sufficient statistics for R2 and MSE, held on the device.
+
+    ``sklearn.metrics.r2_score(..., multioutput=...)`` (train.py:127, test.py:106) needs only
+    n, sum(y), sum(y^2) and sum((y - yhat)^2) per output; fp64 accumulators, one host read at the end.
+    """
+
+    def __init__(self, outputs: int, device):
+        self.buf = torch.zeros(3 * outputs + 2, dtype=torch.float64, device=device)   # sy | syy | sse | n | loss*n
+        self.o = outputs
+
+    def update(self, y: torch.Tensor, yhat: torch.Tensor, loss: Optional[torch.Tensor] = None):
+        y = y.detach().to(torch.float64)
+        d = y - yhat.detach().to(torch.float64)
+        n = y.shape[0]
+        o = self.o
+        self.buf[:o] += y.sum(0)
+        self.buf[o:2 * o] += (y * y).sum(0)
+        self.buf[2 * o:3 * o] += (d * d).sum(0)
+        self.buf[3 * o] += n
+        if loss is not None:
+            self.buf[3 * o + 1] += loss.detach().to(torch.float64) * n
+
+    def all_reduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+
+    def result(self, scale: Optional[torch.Tensor] = None) -> Dict[str, object]:
+        """``scale`` (per-output max-min) reports MSE in descaled units (test.py:93-108); R2 is invariant."""
+        b = self.buf.cpu()
+        o = self.o
+        n = float(b[3 * o])
+        if n == 0:
+            nan = float("nan")
+            return {"n": 0, "r2_raw": [nan] * o, "r2": nan, "mse_raw": [nan] * o, "loss_sum": 0.0}
+        sy, syy, sse = b[:o], b[o:2 * o], b[2 * o:3 * o]
+        sst = syy - sy * sy / n
+        # sklearn: constant target -> 1.0 if perfect else 0.0
+        r2 = torch.where(sst > 0, 1.0 - sse / sst.clamp_min(1e-300),
+                         torch.where(sse == 0, torch.ones_like(sse), torch.zeros_like(sse)))
+        mse = sse / n
+        if scale is not None:
+            mse = mse * scale.to(torch.float64).cpu() ** 2
+        return {"n": int(n), "r2_raw": r2.tolist(), "r2": float(r2.mean()), "mse_raw": mse.tolist(),
+                "loss_sum": float(b[3 * o + 1])}
+
+
+def _targets_topological(model, data, out_dim):
+    out = model(data)
+    return out, data.y.view(-1, out_dim)
+
+
+def _targets_lightpath(model, data, out_dim):
+    out, lut_batch = model(data)            # ValueError when the batch has no LUT node (models.py:35-36)
+    return out, data.y.view(-1, out_dim)[lut_batch]
+
+
+_KINDS = {"topological": _targets_topological, "lightpath": _targets_lightpath}
+
+
+@dataclass
+class History:
+    loss: List[float] = field(default_factory=list)
+    val_loss: List[float] = field(default_factory=list)
+    r2: List[float] = field(default_factory=list)
+    val_r2: List[float] = field(default_factory=list)
+    skipped_graphs: int = 0
+    stopped_early: bool = False
+    best_val_r2: float = float("-inf")
+    epochs_run: int = 0
+
+    def dump(self, directory: str):
+        """loss_history.json etc. as the reference writes them (train.py:213-226)."""
+        os.makedirs(directory, exist_ok=True)
+        for name, vals in (("loss_history", self.loss), ("val_loss_history", self.val_loss),
+                           ("r2_history", self.r2), ("val_r2_history", self.val_r2)):
+            with open(os.path.join(directory, name + ".json"), "w") as f:
+                json.dump(vals, f)
+
+
+def _rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _local_indices(idx: range, batch_size: int, rank: int, world: int) -> List[int]:
+    """Every global batch of ``batch_size`` graphs is cut into contiguous per-rank ranges."""
+    if world == 1:
+        return list(idx)
+    out: List[int] = []
+    for b0 in range(0, len(idx), batch_size):
+        n = min(batch_size, len(idx) - b0)
+        lo, hi = graph_range(n, rank, world)
+        out.extend(idx[b0 + lo:b0 + hi])
+    return out
+
+
+def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out_dim: int, device,
+              criterion, flat: Optional[FlatModel] = None, opt: Optional[FusedSGD] = None) -> Dict[str, object]:
+    """One pass over ``indices``; trains when ``opt`` is given, else evaluates under ``no_grad``."""
+    fwd = _KINDS[kind]
+    rank, world = _rank_world()
+    local_bs = max(1, batch_size // world)
+    loader = GraphLoader(dataset, local_bs, shuffle=False, device=device,
+                         indices=_local_indices(indices, batch_size, rank, world))
+    stats = RegressionStats(out_dim, device)
+    skipped = 0
+    training = opt is not None
+    model.train(training)
+    with torch.set_grad_enabled(training):
+        for data in loader:
+            if training:
+                flat.zero_grad()
+            try:
+                out, y = fwd(model, data, out_dim)
+            except ValueError:
+                skipped += data.num_graphs          # lightpath_training/train.py:118-121
+                if training and world > 1:          # keep the collective count equal on every rank
+                    flat.all_reduce_grads(weight=torch.zeros((), device=device))
+                continue
+            loss = criterion(out, y)
+            if training:
+                loss.backward()
+                if world > 1:
+                    flat.all_reduce_grads(weight=torch.tensor(float(y.shape[0]), device=device))
+                opt.step()
+            stats.update(y, out, loss)
+    stats.all_reduce()
+    res = stats.result()
+    # the reference divides by len(loader.dataset), skipped graphs included (train.py:119)
+    res["avg_loss"] = res["loss_sum"] / max(len(indices), 1)
+    res["skipped"] = skipped
+    return res
+
+
+def fit(model, dataset, *, kind: str = "topological", batch_size: int = 512, num_epochs: int = 35,
+        patience: int = 10, lr: float = 0.1, momentum: float = 0.9, step_size: int = 10, gamma: float = 0.5,
+        chunk_fraction: float = 0.10, output_dim: int = 3, device="cuda", best_path: Optional[str] = None,
+        log: Callable[[str], None] = print) -> History:
+    """The training script's main loop (train.py:24-182) on a dataset object indexable by graph."""
+    device = torch.device(device)
+    model.to(device)
+    tr, va, _ = split_ranges(len(dataset))
+    flat = FlatModel(model)
+    flat.broadcast_params()
+    opt = FusedSGD(flat, lr=lr, momentum=momentum)
+    criterion = torch.nn.SmoothL1Loss()
+    hist = History()
+    rank, _ = _rank_world()
+    counter = 0
+    for epoch in range(num_epochs):
+        chunk = epoch_chunk(epoch, len(tr), chunk_fraction)
+        if epoch == 0:
+            log(f"Training model with {len(chunk)} samples and validating with {len(va)} samples.")
+        opt.lr = step_lr(lr, epoch, step_size, gamma)
+        t = run_epoch(model, dataset, range(tr[0] + chunk[0], tr[0] + chunk[-1] + 1) if len(chunk) else range(0),
+                      kind=kind, batch_size=batch_size, out_dim=output_dim, device=device, criterion=criterion,
+                      flat=flat, opt=opt)
+        v = run_epoch(model, dataset, va, kind=kind, batch_size=batch_size, out_dim=output_dim, device=device,
+                      criterion=criterion)
+        hist.loss.append(t["avg_loss"]); hist.r2.append(t["r2"])
+        hist.val_loss.append(v["avg_loss"]); hist.val_r2.append(v["r2"])
+        hist.skipped_graphs += t["skipped"]
+        hist.epochs_run = epoch + 1
+        log(f"Epoch {epoch + 1}, Loss: {t['avg_loss']:.4f}, R2 Score: {t['r2']:.4f}, "
+            f"Val Loss: {v['avg_loss']:.4f}, Val R2 Score: {v['r2']:.4f}")
+        if v["r2"] > hist.best_val_r2:
+            hist.best_val_r2 = v["r2"]
+            counter = 0
+            if best_path and rank == 0:
+                torch.save(model.state_dict(), best_path)
+        else:
+            counter += 1
+            if counter >= patience:
+                log("Early stopping triggered.")
+                hist.stopped_early = True
+                break
+    return hist
+
+
+def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: str = "topological",
+             batch_size: int = 512, output_dim: int = 3, device="cuda",
+             output_keys: Sequence[str] = ("osnr", "snr", "ber"),
+             target_ranges: Dict[str, Dict[str, float]] = TARGET_RANGES) -> Dict[str, Dict[str, float]]:
+    """test.py's metric block: per-output R2 and MSE on min-max descaled values (test.py:76-121)."""
+    device = torch.device(device)
+    model.to(device)
+    idx = range(len(dataset)) if indices is None else indices
+    fwd = _KINDS[kind]
+    stats = RegressionStats(output_dim, device)
+    model.eval()
+    rank, world = _rank_world()
+    loader = GraphLoader(dataset, max(1, batch_size // world), shuffle=False, device=device,
+                         indices=_local_indices(idx, batch_size, rank, world))
+    with torch.no_grad():
+        for data in loader:
+            try:
+                out, y = fwd(model, data, output_dim)
+            except ValueError:
+                continue
+            stats.update(y, out)
+    stats.all_reduce()
+    scale = torch.tensor([target_ranges[k]["max"] - target_ranges[k]["min"] for k in output_keys][:output_dim],
+                         dtype=torch.float64)
+    res = stats.result(scale)
+    return {k.upper(): {"R2": res["r2_raw"][i], "Test_MSE": res["mse_raw"][i]}
+            for i, k in enumerate(list(output_keys)[:output_dim])}
+
+
+def next_model_path(root_dir: str) -> Tuple[str, int]:
+    """``model_<k>.pth`` with k = 1 + the largest index present (train.py:185-195)."""
+    os.makedirs(root_dir, exist_ok=True)
+    idx = [int(n.split("_")[1].split(".")[0]) for n in os.listdir(root_dir) if n.startswith("model_")]
+    k = max(idx) + 1 if idx else 0
+    return os.path.join(root_dir, f"model_{k}.pth"), k
+
+
+def save_checkpoint(path: str, model, model_params: Dict[str, object]):
+    """The dictionary the reference test scripts expect (train.py:196-209, test.py:47-70)."""
+    torch.save({"model_state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                "model_params": dict(model_params)}, path)
+
+
+def load_checkpoint(path: str):
+    """Reads a checkpoint written by this module or by the reference (tensors + plain containers only)."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    return ck["model_state_dict"], ck["model_params"]

@@ -204,24 +204,35 @@ class GraphLoader:
     """
 
     def __init__(self, dataset: Sequence[Data], batch_size: int, shuffle: bool = False, drop_last: bool = False,
-                 device="cuda", depth: int = 2, generator: Optional[torch.Generator] = None):
+                 device="cuda", depth: int = 2, generator: Optional[torch.Generator] = None,
+                 indices: Optional[Sequence[int]] = None):
+        """``indices`` restricts the loader to a subset of ``dataset`` (the role of
+        ``torch.utils.data.Subset`` at ``topological_training/train.py:34-36,89``) without wrapping
+        it, so a pinned ``PackedGraphs`` keeps its zero-collate path for consecutive ranges."""
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
         self.device = torch.device(device)
         self.generator = generator
+        self.indices = None if indices is None else list(indices)
         self.cuda = self.device.type == "cuda"
         self.depth = max(2, depth) if self.cuda else 1
         self._stages = [_Staging(self.device, pin=True) for _ in range(self.depth)] if self.cuda else []
         self._copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
 
+    @property
+    def num_samples(self) -> int:
+        return len(self.dataset) if self.indices is None else len(self.indices)
+
     def __len__(self) -> int:
-        n = len(self.dataset)
+        n = self.num_samples
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _order(self) -> List[int]:
-        n = len(self.dataset)
-        return torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        base = list(range(len(self.dataset))) if self.indices is None else self.indices
+        if not self.shuffle:
+            return list(base)
+        return [base[i] for i in torch.randperm(len(base), generator=self.generator).tolist()]
 
     def _stage(self, idx: Sequence[int], slot: int) -> Batch:
         packed = isinstance(self.dataset, PackedGraphs)
