@@ -7,11 +7,11 @@ underneath is replaced by hand-written gfx950 HIP kernels in ``libqot_gnn.so``
 (C ABI: ``include/qot_gnn.h``).
 """
 from .batch import Batch, Data, shard_graphs
-from . import harness
+from . import dataset, harness
 from .lightpath import LightpathGNN
 from .loader import GraphLoader, PackedGraphs
 from .nn import BatchNorm, GATConv, NNConv, TransformerConv, global_mean_pool
 from .topological import TopologicalGNN
 
 __all__ = ["Batch", "Data", "shard_graphs", "TopologicalGNN", "LightpathGNN", "TransformerConv", "NNConv",
-           "GATConv", "BatchNorm", "global_mean_pool", "GraphLoader", "PackedGraphs", "harness"]
+           "GATConv", "BatchNorm", "global_mean_pool", "GraphLoader", "PackedGraphs", "harness", "dataset"]
