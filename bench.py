@@ -71,6 +71,8 @@ class TrainStep:
 
     def __init__(self, model, batch, world, use_graph):
         from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+        global QF
+        from gnn_qot_estimation_amd import functional as QF
         self.model, self.batch, self.world = model, batch, world
         self.flat = FlatModel(model)
         self.flat.broadcast_params()
@@ -86,10 +88,10 @@ class TrainStep:
             self.batch._qot_cache = {}       # graph prep (CSR/CSC build) is part of every step
         self.flat.detach_grads()             # zero_grad(set_to_none=True): autograd assigns, no add kernels
         out = self.model(self.batch)
-        loss = F.smooth_l1_loss(out, self.y)
-        loss.backward()
+        # SmoothL1Loss value + gradient from one kernel, then backward from the model output
+        _, g = QF.smooth_l1_loss_and_grad(out, self.y, loss_out=self.loss)
+        out.backward(g)
         self.flat.gather_grads()             # one kernel packs all gradients into the flat buffer
-        self.loss.copy_(loss.detach())
 
     def _eager(self):
         self._fwd_bwd()
@@ -107,6 +109,11 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
+        if self.world == 1:                  # no exchange step: the optimizer rides in the same graph
+            with torch.cuda.graph(self.graph_fb):
+                self._fwd_bwd()
+                self.opt.step()
+            return
         with torch.cuda.graph(self.graph_fb):
             self._fwd_bwd()
         self.graph_opt = torch.cuda.CUDAGraph()
@@ -118,8 +125,9 @@ class TrainStep:
             self._eager()
         else:
             self.graph_fb.replay()
-            self.flat.all_reduce_grads()
-            self.graph_opt.replay()
+            if self.graph_opt is not None:
+                self.flat.all_reduce_grads()
+                self.graph_opt.replay()
 
 
 def event_time_ms(fn, iters=20, warm=3):
@@ -178,7 +186,7 @@ def kernel_table(model, batch):
     ws_a = torch.empty(lib.qot_nnconv_adjoint_dw_workspace_floats(D), device=dev)
     add("nnconv_adjoint_dw", lambda: _lib.call("qot_nnconv_adjoint_dw", P(gout), H, P(x), H, P(ea), P(w1), P(b1),
                                                P(g.rowptr_t), P(g.col_t), P(g.eid_t), P(g.invdeg), P(wp), P(out),
-                                               P(gwt), P(ws_a), N, H, D),
+                                               P(gwt), 0, P(ws_a), N, H, D),
         conv_in + 2 * N * H * 4 + 2 * KT * H * 4, 4.0 * N * KT * H, "mfma")
     add("nnconv_gradh_fused", lambda: _lib.call("qot_nnconv_gradh_fused", P(gout), H, P(x), H, P(ea), P(w1), P(b1),
                                                 P(g.rowptr), P(g.col), P(g.eid), P(g.invdeg), P(bp), P(gw1), P(gb1),

@@ -48,8 +48,8 @@ SIGNATURES = {
     "qot_gemm_tn_workspace_floats": (_sz, [_int]),
     "qot_gemm_tn": (_int, [_p, _int, _p, _int, _i64, _int, _p, _p, _p]),
     "qot_nnconv_adjoint_dw_workspace_floats": (_sz, [_int]),
-    "qot_nnconv_adjoint_dw": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
-                                     _int, _p]),
+    "qot_nnconv_adjoint_dw": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64,
+                                     _int, _int, _p]),
     "qot_nnconv_gradh_workspace_floats": (_sz, [_int]),
     "qot_nnconv_gradh_fused": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int,
                                       _int, _p]),
@@ -76,6 +76,11 @@ SIGNATURES = {
     "qot_head_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
     "qot_head_bwd_workspace_floats": (_sz, [_int, _int]),
     "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
+    "qot_smooth_l1_workspace_floats": (_sz, []),
+    "qot_smooth_l1": (_int, [_p, _p, _i64, _f, _p, _p, _p, _p]),
+    "qot_table_project_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
+    "qot_table_project_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
+    "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),
 }

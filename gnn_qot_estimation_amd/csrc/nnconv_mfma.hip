@@ -519,6 +519,29 @@ __global__ void adj_slab_reduce_kernel(const float* __restrict__ slabs, int nsla
     st4(dst + blockIdx.y * dst_stride + 4 * t, acc);
 }
 
+// final slab sum written straight into the parameters' own layouts (no permute/copy kernels after):
+//   dst = [ g(nn.2.weight)[a*64+o, k] (64*64*K) | g(nn.2.bias)[a*64+o] (64*64) | g(lin.weight)[o, a] (64*64) ]
+// from gWcat^T[kb*64 + o][a]
+__global__ void adj_slab_final_params_kernel(const float* __restrict__ slabs, int nslabs, int64_t elems,
+                                             int64_t slab_stride, float* __restrict__ dst, int K) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t * 4 >= elems) return;
+    float4 acc = f4zero();
+    for (int sidx = 0; sidx < nslabs; ++sidx) acc = add4(acc, ld4(slabs + (int64_t)sidx * slab_stride + 4 * t));
+    const int64_t e = 4 * t;
+    const int a0 = (int)(e & 63), o = (int)((e >> 6) & 63), kb = (int)(e >> 12);
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int a = a0 + c;
+        int64_t idx;
+        if (kb < K) idx = ((int64_t)a * 64 + o) * K + kb;
+        else if (kb == K) idx = (int64_t)4096 * K + a * 64 + o;
+        else idx = (int64_t)4096 * (K + 1) + o * 64 + a;
+        dst[idx] = v[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // grad of the edge MLP's first layer (nn.0.weight / nn.0.bias), fused.
 //   dL/dh_e[k] = invdeg_i * < GA_i[k,:], x_j > ,  GA_i[k,a] = sum_o g_i[o] * W2[a*64+o, k]
@@ -830,7 +853,8 @@ extern "C" int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const floa
                                      const float* edge_attr, const float* w1, const float* b1,
                                      const int32_t* rowptr_t, const int32_t* col_t, const int32_t* eid_t,
                                      const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t,
-                                     float* workspace, int64_t N, int H, int D, qot_stream_t stream_) {
+                                     int param_layout, float* workspace, int64_t N, int H, int D,
+                                     qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N <= 0 || !rowptr_t) return QOT_ERR_BADARG;
     if (H != 64 || D > 4) return QOT_ERR_UNSUPPORTED;
@@ -852,8 +876,12 @@ extern "C" int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const floa
     adj_slab_reduce_kernel<<<dim3(grid_for(elems / 4, 256), groups), 256, 0, stream>>>(
         workspace, grid, per_group, elems, elems, workspace, (int64_t)per_group * elems);
     QOT_LAUNCH_CHECK();
-    adj_slab_reduce_kernel<<<dim3(grid_for(elems / 4, 256), 1), 256, 0, stream>>>(
-        workspace, groups, groups, elems, (int64_t)per_group * elems, gwcat_t, 0);
+    if (param_layout)
+        adj_slab_final_params_kernel<<<grid_for(elems / 4, 256), 256, 0, stream>>>(
+            workspace, groups, elems, (int64_t)per_group * elems, gwcat_t, 2 * D);
+    else
+        adj_slab_reduce_kernel<<<dim3(grid_for(elems / 4, 256), 1), 256, 0, stream>>>(
+            workspace, groups, groups, elems, (int64_t)per_group * elems, gwcat_t, 0);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

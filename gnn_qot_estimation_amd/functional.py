@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 import os
+from typing import Optional
 
 import torch
 
@@ -142,6 +143,58 @@ class SmallLinearFn(torch.autograd.Function):
         gx = _small_gemm(g, weight, None, m, k, n, n, 1, k, 1) if ctx.needs_input_grad[0] else None   # g @ W
         gw = _small_gemm(g, x, None, n, k, m, 1, n, k, 1)                  # g^T @ x: A(i,r) = g[r,i]
         return gx, gw, colsum(g) if m >= 64 else g.sum(0)
+
+
+class TableProjectFn(torch.autograd.Function):
+    """``[q|k|v|skip] = table @ W^T + b`` for the ``[V, H]`` embedding table from the four Linear
+    parameters in place (one launch; backward one launch for all nine gradients)."""
+
+    @staticmethod
+    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs):
+        require_cuda(table, wq, bq, wk, bk, wv, bv, ws, bs)
+        table, wq, bq, wk, bk, wv, bv, ws, bs = (_f32c(t) for t in (table, wq, bq, wk, bk, wv, bv, ws, bs))
+        V, H = table.shape
+        out = torch.empty(V, 4 * H, dtype=torch.float32, device=table.device)
+        _lib.call("qot_table_project_fwd", P(table), P(wq), P(bq), P(wk), P(bk), P(wv), P(bv), P(ws), P(bs), P(out),
+                  V, H)
+        ctx.save_for_backward(table, wq, wk, wv, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        table, wq, wk, wv, ws = ctx.saved_tensors
+        g = _f32c(g)
+        V, H = table.shape
+        dev = g.device
+        gt = torch.empty(V, H, dtype=torch.float32, device=dev)
+        gw = torch.empty(4 * H, H, dtype=torch.float32, device=dev)
+        gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        _lib.call("qot_table_project_bwd", P(g), P(table), P(wq), P(wk), P(wv), P(ws), P(gt), P(gw), P(gb), V, H)
+        return (gt, gw[:H], gb[:H], gw[H:2 * H], gb[H:2 * H], gw[2 * H:3 * H], gb[2 * H:3 * H], gw[3 * H:],
+                gb[3 * H:])
+
+
+_LOSS_WS = {}
+
+
+def smooth_l1_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, beta: float = 1.0,
+                            loss_out: Optional[torch.Tensor] = None):
+    """``SmoothL1Loss()(pred, target)`` (mean) and ``d loss / d pred`` from ONE kernel
+    (criterion of ``topological_training/train.py:69``).  Use as
+    ``loss, g = smooth_l1_loss_and_grad(out, y); out.backward(g)`` -- the separate loss / mean /
+    ones-fill / backward-elementwise launches of the autograd route are gone."""
+    require_cuda(pred, target)
+    p, t = _f32c(pred.detach()), _f32c(target.detach())
+    if p.shape != t.shape:
+        raise ValueError(f"shape mismatch {tuple(p.shape)} vs {tuple(t.shape)}")
+    dev = p.device
+    ws = _LOSS_WS.get(dev)
+    if ws is None:
+        ws = _LOSS_WS[dev] = torch.zeros(_lib.load().qot_smooth_l1_workspace_floats(), dtype=torch.float32, device=dev)
+    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(p)
+    _lib.call("qot_smooth_l1", P(p), P(t), p.numel(), float(beta), P(loss), P(grad), P(ws))
+    return loss, grad
 
 
 # ------------------------------------------------------------------ TransformerConv (a2)
@@ -300,8 +353,17 @@ def nnconv_fused_indices(k: int, device):
         fwd = wcat_idx.reshape(-1)[nnconv_perm_index((k + 2) * h, "cpu")]
         adj = wcat_t_idx.reshape(-1)[nnconv_perm_index((k + 2) * h, "cpu")]
         gh = wcat_idx[:k * h].reshape(-1)[nnconv_gradh_perm_index(k, "cpu")]
-        _PERM_CACHE[key] = tuple(t.contiguous().to(device) for t in (fwd, adj, gh))
+        allidx = torch.cat([fwd, adj, gh]).to(torch.int32).contiguous().to(device)
+        _PERM_CACHE[key] = (allidx, fwd.numel(), adj.numel(), gh.numel())
     return _PERM_CACHE[key]
+
+
+def nnconv_pack_operands(w2, b2, wroot, k: int):
+    """(Wcat, WcatT, Wk^T) in MFMA fragment order straight from the three parameters: one launch."""
+    allidx, n_f, n_a, n_g = nnconv_fused_indices(k, w2.device)
+    packed = torch.empty(allidx.numel(), dtype=torch.float32, device=w2.device)
+    _lib.call("qot_gather3", P(w2), w2.numel(), P(b2), b2.numel(), P(wroot), P(allidx), P(packed), allidx.numel())
+    return packed[:n_f], packed[n_f:n_f + n_a], packed[n_f + n_a:]
 
 
 def _fused_ok(hin, hout):
@@ -323,10 +385,9 @@ class NNConvFn(torch.autograd.Function):
             raise _lib.QotError("NNConv edge MLP must be Linear(D, 2D) -> ReLU -> Linear(2D, Hin*Hout)")
         if edge_attr.shape != (graph.num_edges_in, D):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
-        pflat = None
+        wp = wp_adj = bp = None
         if _fused_ok(hin, hout):
-            pflat = torch.cat([w2.reshape(-1), b2.reshape(-1), wroot.reshape(-1)])
-            wp = pflat[nnconv_fused_indices(K, x.device)[0]]
+            wp, wp_adj, bp = nnconv_pack_operands(w2, b2, wroot, K)
             out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
             _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
@@ -340,7 +401,7 @@ class NNConvFn(torch.autograd.Function):
                 pre = out
                 out = torch.empty_like(pre)
                 _lib.call("qot_act_fwd", P(pre), P(out), pre.numel(), *_act_args(act)[1:])
-        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, pflat, out if act is not None else None,
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, out if act is not None else None,
                               act[3] if act is not None else None)
         ctx.graph = graph
         ctx.act = None if act is None else (act[0], act[1], act[2])
@@ -348,7 +409,7 @@ class NNConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x, edge_attr, w1, b1, w2, b2, wroot, A, pflat, y, act_step = ctx.saved_tensors
+        x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, y, act_step = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g)
         if ctx.act is not None:
@@ -358,17 +419,18 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         gbias = colsum(g)
-        fused_all = _fused_ok(hin, hout) and D <= 4 and pflat is not None and not os.environ.get("QOT_SPLIT_NNCONV_BWD")
+        fused_all = _fused_ok(hin, hout) and D <= 4 and wp_adj is not None and not os.environ.get("QOT_SPLIT_NNCONV_BWD")
         wcat_t = None if fused_all else nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
         if fused_all:
             # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U
-            wp = pflat[nnconv_fused_indices(K, dev)[1]]
             gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
-            gwt = torch.empty((K + 2) * hout, hin, dtype=torch.float32, device=dev)
+            gpar = torch.empty((K + 2) * hout * hin, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp), P(gx), P(gwt), P(ws), N, hin, D)
-            gwcat = gwt.view(K + 2, hout, hin).transpose(1, 2).reshape((K + 2) * hin, hout)
+                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 1, P(ws), N, hin, D)
+            # already in the parameters' own layouts (no permute / copy kernels)
+            hh = hin * hout
+            gw2, gb2, gwroot = gpar[:hh * K].view(hh, K), gpar[hh * K:hh * (K + 1)], gpar[hh * (K + 1):].view(hout, hin)
         else:
             if A is None:      # fused forward did not materialise the operand: rebuild it for dW
                 A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
@@ -387,14 +449,13 @@ class NNConvFn(torch.autograd.Function):
                 _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                           P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
                 gx = U @ wcat_t
-        gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
-        gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
-        gwroot = gwcat[(K + 1) * hin:].t()
+            gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
+            gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
+            gwroot = gwcat[(K + 1) * hin:].t()
         # grad of the edge MLP's first layer
         if hin != hout:
             raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
-        if _fused_ok(hin, hout) and D <= 4 and pflat is not None:
-            bp = pflat[nnconv_fused_indices(K, dev)[2]]
+        if _fused_ok(hin, hout) and D <= 4 and bp is not None:
             gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
             gb1 = torch.empty(K, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)

@@ -65,8 +65,9 @@ class TransformerConv(nn.Module):
     def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None):
         """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
         ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows."""
-        w, b = self.packed_weight()
-        t4 = QF.SmallLinearFn.apply(table, w, b)      # [V, 4H]
+        t4 = QF.TableProjectFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                     self.lin_key.bias, self.lin_value.weight, self.lin_value.bias,
+                                     self.lin_skip.weight, self.lin_skip.bias)      # [V, 4H]
         return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps, act)
 
 

@@ -162,12 +162,14 @@ int qot_gemm_tn(const float* A, int lda, const float* G, int ldg, int64_t N, int
  * (as qot_nnconv_fused transpose=1) and gwcat_t = per-block transposes of d/dWcat
  * (gwcat_t[k*64+o][a] = dWcat[k*64+a][o]) computed as X^T U from the same LDS tile.  Replaces
  * {qot_nnconv_fused(transpose=1), qot_nnconv_agg, qot_gemm_tn}.  x = the forward input rows.
+ * param_layout = 1 writes the weight gradient in the parameters' own layouts instead:
+ * [d nn.2.weight [H*H, K] | d nn.2.bias [H*H] | d lin.weight [H, H]] (same total size).
  * workspace: qot_nnconv_adjoint_dw_workspace_floats(D) floats. */
 size_t qot_nnconv_adjoint_dw_workspace_floats(int D);
 int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const float* x, int ld_x,
                           const float* edge_attr, const float* w1, const float* b1,
                           const int32_t* rowptr_t, const int32_t* col_t, const int32_t* eid_t,
-                          const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t,
+                          const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t, int param_layout,
                           float* workspace, int64_t N, int H, int D, qot_stream_t stream);
 /* Fused form of {GA = g @ Wk^T ; qot_nnconv_bwd_edge} for H == 64, D <= 4: the GA tile is produced
  * by MFMA into LDS and consumed there.  b_perm: Wk^T in fragment order (csrc/nnconv_mfma.hip).
@@ -271,6 +273,30 @@ int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden
                  const float* w0, const float* w3, float* grad_x, float* grads, float* workspace, int64_t B,
                  int H, int O, float slope, float p, uint64_t seed, const int64_t* step_counter,
                  qot_stream_t stream);
+
+/* ---- SmoothL1Loss(reduction="mean", beta) value and gradient in one launch
+ * (criterion at topological_training/train.py:69, used at :113-115).  grad = d loss / d pred.
+ * workspace: qot_smooth_l1_workspace_floats() floats whose first word is 0 before the first call
+ * (the kernel leaves it 0). */
+size_t qot_smooth_l1_workspace_floats(void);
+int qot_smooth_l1(const float* pred, const float* target, int64_t n, float beta, float* loss, float* grad,
+                  float* workspace, qot_stream_t stream);
+
+/* ---- embedding-table projection for TransformerConv table mode: out[V,4H] = [q|k|v|skip] rows of
+ * table[V,H] under lin_query/lin_key/lin_value/lin_skip (topological_training/models.py:51-53 with
+ * x = node_embeddings(node_ids)); reads the four Linear parameters in place.
+ * bwd: grad_table[V,H], grad_w[4H,H] and grad_b[4H] in q|k|v|skip order. */
+int qot_table_project_fwd(const float* table, const float* wq, const float* bq, const float* wk, const float* bk,
+                          const float* wv, const float* bv, const float* ws, const float* bs, float* out, int V,
+                          int H, qot_stream_t stream);
+int qot_table_project_bwd(const float* grad_out, const float* table, const float* wq, const float* wk,
+                          const float* wv, const float* ws, float* grad_table, float* grad_w, float* grad_b, int V,
+                          int H, qot_stream_t stream);
+
+/* ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]]: one gather builds the fragment-ordered NNConv
+ * operands from nn.2.weight / nn.2.bias / lin.weight (topological_training/models.py:20-25). */
+int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const float* s2, const int32_t* idx,
+                float* out, int64_t n, qot_stream_t stream);
 
 /* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
 int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,
