@@ -1,9 +1,9 @@
 // Graph preparation: int64 edge_index -> int32 CSR-by-destination + CSC-by-source.
 // Replaces the per-call index bookkeeping PyG's MessagePassing.propagate does for
 // topological_training/models.py:53,57 and lightpath_training/models.py:30 (including
-// GATConv's remove_self_loops/add_self_loops rebuild).  Stable LSD radix sort (rocPRIM)
-// keeps the original edge order inside every destination, so every later segmented
-// reduction has a fixed summation order (bitwise reproducible, no atomics).
+// GATConv's remove_self_loops/add_self_loops rebuild).  Counting sort + per-row ordering by
+// edge id keeps the original edge order inside every destination and every source, so every
+// later segmented reduction has a fixed summation order (bitwise reproducible).
 #include "common.hpp"
 
 namespace qot {
@@ -11,92 +11,97 @@ namespace qot {
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 // ---- counting sort by destination (CSR) and by source (CSC) -------------------------------
-// 1. histogram of in-/out-degrees (int atomics)          2. exclusive scans -> rowptr, rowptr_t
-// 3. slots claimed with an atomic cursor per row (unordered inside a row)
-// 4. one thread per row insertion-sorts its slots by original edge id, so the order inside a
-//    destination is the caller's edge order whatever the atomics did: every later segmented
-//    sum has a fixed order (bitwise run-to-run reproducible).  Rows are short (in-degree ~4,
-//    <= 64 in the power-law config); the sort is O(d^2) per row.
-// GAT mode: edges with j == i are dropped, node n gets slot key E + n (sorts last, eid -1).
+// 1. degree histograms; the value each int atomic returns is the edge's (arbitrary) rank inside
+//    its destination / source row, kept per edge                      (edge-parallel)
+// 2. exclusive scans -> rowptr, rowptr_t
+// 3. keys placed at rowptr[row] + rank: no second round of atomics    (edge-parallel)
+// 4. one thread per row (N destination rows + N source rows in one launch) insertion-sorts its
+//    keys by original edge id, so the order inside a row is the caller's edge order whatever the
+//    atomics did: every later segmented sum has a fixed order (bitwise run-to-run reproducible).
+//    Rows are short (degree ~4, <= 64 in the power-law config); the sort is O(d^2) per row.
+// 5. pos_t[t] = CSR slot of out-edge t                                (edge-parallel)
+// GAT mode: edges with j == i are dropped, node n gets key E + n (sorts last, eid -1).
 
 __global__ void csr_hist_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t N, int gat,
-                                int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out, int64_t cap) {
+                                int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
+                                int32_t* __restrict__ rank_in, int32_t* __restrict__ rank_out, int64_t cap) {
     int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= cap) return;
+    int64_t i, j;
     if (e < E) {
-        int64_t j = ei[e], i = ei[E + e];
+        j = ei[e]; i = ei[E + e];
         if (gat && j == i) return;
-        atomicAdd(&cnt_in[i], 1);
-        atomicAdd(&cnt_out[j], 1);
     } else {
-        atomicAdd(&cnt_in[e - E], 1);
-        atomicAdd(&cnt_out[e - E], 1);
+        i = j = e - E;
     }
+    rank_in[e] = atomicAdd(&cnt_in[i], 1);
+    rank_out[e] = atomicAdd(&cnt_out[j], 1);
 }
 
-__global__ void csr_claim_kernel(const int64_t* __restrict__ ei, int64_t E, int gat,
-                                 const int32_t* __restrict__ rowptr, int32_t* __restrict__ cur_in,
-                                 int32_t* __restrict__ slot_key, int64_t cap) {
+__global__ void csr_place_kernel(const int64_t* __restrict__ ei, int64_t E, int gat,
+                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowptr_t,
+                                 const int32_t* __restrict__ rank_in, const int32_t* __restrict__ rank_out,
+                                 int32_t* __restrict__ key_in, int32_t* __restrict__ key_out, int64_t cap) {
     int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (e >= cap) return;
-    int64_t i;
+    int64_t i, j;
     if (e < E) {
-        int64_t j = ei[e];
-        i = ei[E + e];
+        j = ei[e]; i = ei[E + e];
         if (gat && j == i) return;
     } else {
-        i = e - E;
+        i = j = e - E;
     }
-    int p = rowptr[i] + atomicAdd(&cur_in[i], 1);
-    slot_key[p] = (int32_t)e;            // keys >= E are the appended self loops
+    key_in[rowptr[i] + rank_in[e]] = (int32_t)e;       // keys >= E are the appended self loops
+    key_out[rowptr_t[j] + rank_out[e]] = (int32_t)e;
 }
 
-// one thread per destination: sort its slots, emit col/eid/row, claim CSC slots
-__global__ void csr_emit_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t N,
-                                const int32_t* __restrict__ rowptr, int32_t* __restrict__ slot_key,
-                                int32_t* __restrict__ col, int32_t* __restrict__ eid, int32_t* __restrict__ row,
-                                const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ cur_out,
-                                int32_t* __restrict__ pos_t, float* __restrict__ invdeg) {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int beg = rowptr[i], end = rowptr[i + 1];
+__device__ __forceinline__ void sort_row_keys(int32_t* __restrict__ k, int beg, int end) {
     for (int a = beg + 1; a < end; ++a) {
-        int key = slot_key[a];
+        int key = k[a];
         int b = a - 1;
-        while (b >= beg && slot_key[b] > key) { slot_key[b + 1] = slot_key[b]; --b; }
-        slot_key[b + 1] = key;
+        while (b >= beg && k[b] > key) { k[b + 1] = k[b]; --b; }
+        k[b + 1] = key;
     }
-    for (int p = beg; p < end; ++p) {
-        int key = slot_key[p];
-        int j = (key < E) ? (int)ei[key] : (int)(key - E);
-        col[p] = j;
-        eid[p] = (key < E) ? key : -1;
-        row[p] = (int32_t)i;
-        int t = rowptr_t[j] + atomicAdd(&cur_out[j], 1);
-        pos_t[t] = p;
-    }
-    int d = end - beg;
-    invdeg[i] = 1.0f / (float)(d > 1 ? d : 1);
 }
 
-// one thread per source: sort its out-edges by CSR slot, emit col_t / eid_t
-__global__ void csc_emit_kernel(int64_t N, const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ pos_t,
-                                const int32_t* __restrict__ row, const int32_t* __restrict__ eid,
-                                int32_t* __restrict__ col_t, int32_t* __restrict__ eid_t) {
-    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const int beg = rowptr_t[j], end = rowptr_t[j + 1];
-    for (int a = beg + 1; a < end; ++a) {
-        int key = pos_t[a];
-        int b = a - 1;
-        while (b >= beg && pos_t[b] > key) { pos_t[b + 1] = pos_t[b]; --b; }
-        pos_t[b + 1] = key;
+// threads [0, N): destination row i -> col / eid / row / slot_of / invdeg
+// threads [N, 2N): source row j     -> col_t / eid_t, sorted keys stay in key_out (= pos_t buffer)
+__global__ void csr_sort_emit_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t N,
+                                     const int32_t* __restrict__ rowptr, int32_t* __restrict__ key_in,
+                                     int32_t* __restrict__ col, int32_t* __restrict__ eid, int32_t* __restrict__ row,
+                                     int32_t* __restrict__ slot_of, float* __restrict__ invdeg,
+                                     const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ key_out,
+                                     int32_t* __restrict__ col_t, int32_t* __restrict__ eid_t) {
+    int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r < N) {
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        sort_row_keys(key_in, beg, end);
+        for (int p = beg; p < end; ++p) {
+            const int key = key_in[p];
+            col[p] = (key < E) ? (int32_t)ei[key] : (int32_t)(key - E);
+            eid[p] = (key < E) ? key : -1;
+            row[p] = (int32_t)r;
+            slot_of[key] = p;
+        }
+        const int d = end - beg;
+        invdeg[r] = 1.0f / (float)(d > 1 ? d : 1);
+    } else if (r < 2 * N) {
+        const int64_t j = r - N;
+        const int beg = rowptr_t[j], end = rowptr_t[j + 1];
+        sort_row_keys(key_out, beg, end);
+        for (int t = beg; t < end; ++t) {
+            const int key = key_out[t];
+            col_t[t] = (key < E) ? (int32_t)ei[E + key] : (int32_t)(key - E);
+            eid_t[t] = (key < E) ? key : -1;
+        }
     }
-    for (int t = beg; t < end; ++t) {
-        int p = pos_t[t];
-        col_t[t] = row[p];
-        eid_t[t] = eid[p];
-    }
+}
+
+// live slots = rowptr_t[N] (cap minus the self loops GAT mode dropped); the tail is never touched
+__global__ void csc_pos_kernel(int32_t* __restrict__ pos_t, const int32_t* __restrict__ slot_of,
+                               const int32_t* __restrict__ rowptr_t, int64_t N) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < (int64_t)rowptr_t[N]) pos_t[t] = slot_of[pos_t[t]];
 }
 
 // ---- exclusive scan of two int32 arrays (in-degrees, out-degrees), plain kernels only --------
@@ -154,18 +159,28 @@ __global__ __launch_bounds__(256) void scan_chunk_offsets_kernel(int32_t* __rest
     }
 }
 
-// phase C: exclusive scan inside each chunk + chunk offset -> out
+// phase C: exclusive scan inside each chunk + chunk offset -> out.  totals_only: bsum still holds
+// the per-chunk TOTALS (phase B skipped, few chunks) and every block sums the ones before it.
 __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                          int64_t n, const int32_t* __restrict__ bsum, int nchunks,
-                                                         int32_t* __restrict__ out_a, int32_t* __restrict__ out_b) {
+                                                         int totals_only, int32_t* __restrict__ out_a,
+                                                         int32_t* __restrict__ out_b) {
     const int32_t* src = blockIdx.y ? b : a;
     int32_t* dst = blockIdx.y ? out_b : out_a;
     const int64_t base = (int64_t)blockIdx.x * kScanChunk + threadIdx.x * 8;
     int v[8], s = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { v[u] = (base + u < n) ? src[base + u] : 0; s += v[u]; }
+    int offset;
+    if (totals_only) {
+        int part = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += bsum[blockIdx.y * nchunks + c];
+        block_exclusive_scan_256(part, &offset);
+    } else {
+        offset = bsum[blockIdx.y * nchunks + blockIdx.x];
+    }
     int total;
-    int ex = block_exclusive_scan_256(s, &total) + bsum[blockIdx.y * nchunks + blockIdx.x];
+    int ex = block_exclusive_scan_256(s, &total) + offset;
 #pragma unroll
     for (int u = 0; u < 8; ++u) { if (base + u < n) dst[base + u] = ex; ex += v[u]; }
 }
@@ -206,11 +221,11 @@ using namespace qot;
 
 static inline int scan_chunks(int64_t n) { return (int)((n + kScanChunk - 1) / kScanChunk); }
 
-// workspace: cnt_in[N+1] cnt_out[N+1] cur_in[N+1] cur_out[N+1] | slot_key[cap] | bsum[2*nchunks]
+// workspace: cnt_in[N+1] cnt_out[N+1] | rank_in rank_out key_in slot_of [cap each] | bsum[2*nchunks]
 extern "C" size_t qot_csr_workspace_bytes(int64_t E, int64_t N, int gat_self_loops) {
     if (E < 0 || N < 0) return 0;
     int64_t cap = E + (gat_self_loops ? N : 0);
-    return 4 * align256((size_t)(N + 1) * 4) + align256((size_t)(cap > 0 ? cap : 1) * 4) +
+    return 2 * align256((size_t)(N + 1) * 4) + 4 * align256((size_t)(cap > 0 ? cap : 1) * 4) +
            align256((size_t)2 * scan_chunks(N + 1) * 4) + 256;
 }
 
@@ -237,33 +252,42 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
     if (!edge_index && E > 0) return QOT_ERR_BADARG;
     if (!col || !eid || !row || !col_t || !pos_t || !eid_t || !workspace) return QOT_ERR_BADARG;
     const size_t seg = align256((size_t)(N + 1) * 4);
+    const size_t cseg = align256((size_t)cap * 4);
     const int nchunks = scan_chunks(N + 1);
-    const size_t need = 4 * seg + align256((size_t)cap * 4) + align256((size_t)2 * nchunks * 4);
+    const size_t need = 2 * seg + 4 * cseg + align256((size_t)2 * nchunks * 4);
     if (workspace_bytes < need) return QOT_ERR_BADARG;
     char* w = (char*)workspace;
     int32_t* cnt_in = (int32_t*)(w);
     int32_t* cnt_out = (int32_t*)(w + seg);
-    int32_t* cur_in = (int32_t*)(w + 2 * seg);
-    int32_t* cur_out = (int32_t*)(w + 3 * seg);
-    int32_t* slot_key = (int32_t*)(w + 4 * seg);
-    int32_t* bsum = (int32_t*)(w + 4 * seg + align256((size_t)cap * 4));
+    int32_t* rank_in = (int32_t*)(w + 2 * seg);
+    int32_t* rank_out = (int32_t*)(w + 2 * seg + cseg);
+    int32_t* key_in = (int32_t*)(w + 2 * seg + 2 * cseg);
+    int32_t* slot_of = (int32_t*)(w + 2 * seg + 3 * cseg);
+    int32_t* bsum = (int32_t*)(w + 2 * seg + 4 * cseg);
+    int32_t* key_out = pos_t;            // sorted keys live in the pos_t buffer until csc_pos_kernel
 
-    zero_i32_kernel<<<grid_for((int64_t)(4 * seg / 4), T), T, 0, stream>>>((int32_t*)w, (int64_t)(4 * seg / 4));
+    zero_i32_kernel<<<grid_for((int64_t)(2 * seg / 4), T), T, 0, stream>>>((int32_t*)w, (int64_t)(2 * seg / 4));
     QOT_LAUNCH_CHECK();
-    csr_hist_kernel<<<grid_for(cap, T), T, 0, stream>>>(edge_index, E, N, gat_self_loops, cnt_in, cnt_out, cap);
+    csr_hist_kernel<<<grid_for(cap, T), T, 0, stream>>>(edge_index, E, N, gat_self_loops, cnt_in, cnt_out, rank_in,
+                                                        rank_out, cap);
     QOT_LAUNCH_CHECK();
     scan_chunk_sums_kernel<<<dim3(nchunks, 2), T, 0, stream>>>(cnt_in, cnt_out, N + 1, bsum, nchunks);
     QOT_LAUNCH_CHECK();
-    scan_chunk_offsets_kernel<<<2, T, 0, stream>>>(bsum, nchunks);
+    const int totals_only = nchunks <= 2048;
+    if (!totals_only) {
+        scan_chunk_offsets_kernel<<<2, T, 0, stream>>>(bsum, nchunks);
+        QOT_LAUNCH_CHECK();
+    }
+    scan_apply_kernel<<<dim3(nchunks, 2), T, 0, stream>>>(cnt_in, cnt_out, N + 1, bsum, nchunks, totals_only, rowptr,
+                                                          rowptr_t);
     QOT_LAUNCH_CHECK();
-    scan_apply_kernel<<<dim3(nchunks, 2), T, 0, stream>>>(cnt_in, cnt_out, N + 1, bsum, nchunks, rowptr, rowptr_t);
+    csr_place_kernel<<<grid_for(cap, T), T, 0, stream>>>(edge_index, E, gat_self_loops, rowptr, rowptr_t, rank_in,
+                                                         rank_out, key_in, key_out, cap);
     QOT_LAUNCH_CHECK();
-    csr_claim_kernel<<<grid_for(cap, T), T, 0, stream>>>(edge_index, E, gat_self_loops, rowptr, cur_in, slot_key, cap);
+    csr_sort_emit_kernel<<<grid_for(2 * N, T), T, 0, stream>>>(edge_index, E, N, rowptr, key_in, col, eid, row, slot_of,
+                                                               invdeg, rowptr_t, key_out, col_t, eid_t);
     QOT_LAUNCH_CHECK();
-    csr_emit_kernel<<<grid_for(N, T), T, 0, stream>>>(edge_index, E, N, rowptr, slot_key, col, eid, row, rowptr_t,
-                                                      cur_out, pos_t, invdeg);
-    QOT_LAUNCH_CHECK();
-    csc_emit_kernel<<<grid_for(N, T), T, 0, stream>>>(N, rowptr_t, pos_t, row, eid, col_t, eid_t);
+    csc_pos_kernel<<<grid_for(cap, T), T, 0, stream>>>(pos_t, slot_of, rowptr_t, N);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

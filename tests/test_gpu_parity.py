@@ -198,15 +198,16 @@ def test_csr_build_matches_stable_cpu_sort(cuda_device, gat):
     assert torch.equal(g.col.cpu().long()[:m], src[order])
     assert torch.equal(g.eid.cpu().long()[:m], ids[order])
     assert torch.equal(g.row.cpu().long()[:m], dst[order])
-    # CSC: out-edges of j in CSR-slot order
-    csr_src = src[order]
-    order_t = torch.sort(csr_src, stable=True).indices
+    # CSC: out-edges of j in the caller's edge order (appended self loops last); pos_t = CSR slot
+    order_t = torch.sort(src, stable=True).indices
     rowptr_t = torch.zeros(n + 1, dtype=torch.long)
-    rowptr_t[1:] = torch.bincount(csr_src, minlength=n).cumsum(0)
+    rowptr_t[1:] = torch.bincount(src, minlength=n).cumsum(0)
+    slot_of = torch.empty(m, dtype=torch.long)
+    slot_of[order] = torch.arange(m)
     assert torch.equal(g.rowptr_t.cpu().long(), rowptr_t)
-    assert torch.equal(g.pos_t.cpu().long()[:m], order_t)
-    assert torch.equal(g.col_t.cpu().long()[:m], dst[order][order_t])
-    assert torch.equal(g.eid_t.cpu().long()[:m], ids[order][order_t])
+    assert torch.equal(g.pos_t.cpu().long()[:m], slot_of[order_t])
+    assert torch.equal(g.col_t.cpu().long()[:m], dst[order_t])
+    assert torch.equal(g.eid_t.cpu().long()[:m], ids[order_t])
     deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
     assert torch.allclose(g.invdeg.cpu(), 1.0 / deg)
 
