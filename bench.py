@@ -198,9 +198,10 @@ def kernel_table(model, batch):
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
                                            4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,
-                                           off(gq, 0), off(gq, 3 * H), 4 * H, P(escr), P(delta), P(pds), P(pal), N, H, D),
+                                           off(gq, 0), off(gq, 3 * H), 4 * H, P(escr), P(delta), P(pds), P(pal),
+                                           None, 0.0, 0.0, 0, None, None, None, N, H, D),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 8 * E + 4 * N + 8 * N * D)
-    add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), off(qkvs, 0), 4 * H, P(escr), P(delta),
+    add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), H, off(qkvs, 0), 4 * H, P(escr), P(delta),
                                            P(g.rowptr_t), P(g.col_t), P(g.pos_t), None, off(gq, H), off(gq, 2 * H),
                                            4 * H, N, H),
         2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)

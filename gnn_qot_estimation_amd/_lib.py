@@ -37,9 +37,10 @@ SIGNATURES = {
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),
+    "qot_tconv_bwd_dst_workspace_floats": (_sz, [_i64, _int, _int]),
     "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
-                                 _i64, _int, _int, _p]),
-    "qot_tconv_bwd_src": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
+                                 _p, _f, _f, _u64, _p, _p, _p, _i64, _int, _int, _p]),
+    "qot_tconv_bwd_src": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _p]),
     "qot_tconv_wedge_workspace_floats": (_sz, [_int, _int]),
     "qot_tconv_wedge_grad": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "qot_head_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
     "qot_head_bwd_workspace_floats": (_sz, [_int, _int]),
     "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
+    "qot_act_bwd_colsum": (_int, [_p, _p, _p, _i64, _int, _f, _f, _u64, _p, _p, _p, _p]),
     "qot_smooth_l1_workspace_floats": (_sz, []),
     "qot_smooth_l1": (_int, [_p, _p, _i64, _f, _p, _p, _p, _p]),
     "qot_table_project_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),

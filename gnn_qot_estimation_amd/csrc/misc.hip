@@ -288,9 +288,17 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     p[t] = fmaf(-lr, b, p[t]);
 }
 
-// column sums of a row-major [N, C] matrix (bias gradients): per-block slices -> partials -> wave sums
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, int64_t N, int C,
-                                                             float* __restrict__ partials) {
+// column sums of a row-major [N, C] matrix (bias gradients), optionally fused with the backward of
+// dropout(leaky_relu(.)): gx = g * act'(y) is written and ITS column sums are produced -- the bias
+// gradient of a conv whose epilogue carried the activation.  Block partials, then one wave per column
+// sums them in a fixed order (bitwise reproducible).  (A single-launch variant with a last-block
+// ticket was measured 4-8x slower: the agent-scope release fence it needs writes back the L2 lines
+// the same kernel has just dirtied with gx.)
+template <bool ACT>
+__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ g, int ld,
+                                                           const float* __restrict__ y, float* __restrict__ gx,
+                                                           int64_t N, int C, ActParams act,
+                                                           float* __restrict__ partials) {
     __shared__ float4 red[256];
     const int C4 = C / 4;
     const int RPB = 256 / C4;
@@ -300,7 +308,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int64_t r1 = (r0 + per < N) ? r0 + per : N;
     float4 acc = f4zero();
     if (slot < RPB)
-        for (int64_t r = r0 + slot; r < r1; r += RPB) acc = add4(acc, ld4(x + r * ld + 4 * sub));
+        for (int64_t r = r0 + slot; r < r1; r += RPB) {
+            float4 v = ld4(g + r * ld + 4 * sub);
+            if (ACT) {
+                const int64_t flat = r * C + 4 * sub;
+                const float4 yy = ld4(y + flat);
+                uint64_t z = 0;
+                if (act.thr16) z = act_hash64(act.seed, (uint64_t)act.step[0], (uint64_t)flat >> 2);
+                float vi[4] = {v.x, v.y, v.z, v.w};
+                const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool keep = act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= act.thr16) : true;
+                    vi[c] = vi[c] * (keep ? act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : act.slope);
+                }
+                v = make_float4(vi[0], vi[1], vi[2], vi[3]);
+                st4(gx + flat, v);
+            }
+            acc = add4(acc, v);
+        }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < C4) {
@@ -438,16 +464,37 @@ extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum
 
 extern "C" size_t qot_colsum_workspace_floats(int C) { return (size_t)kColsumBlocks * (size_t)(C > 0 ? C : 0); }
 
+static int colsum_blocks(int64_t N) {
+    int blocks = kColsumBlocks;
+    if (N < (int64_t)blocks * 4) blocks = (int)((N + 3) / 4);
+    return blocks;
+}
+
 extern "C" int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace,
                           qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N <= 0 || !x || !out || !workspace || (ld & 3)) return QOT_ERR_BADARG;
     if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
-    int blocks = kColsumBlocks;
-    if (N < (int64_t)blocks * 4) blocks = (int)((N + 3) / 4);
-    colsum_partial_kernel<<<blocks, 256, 0, stream>>>(x, ld, N, C, workspace);
+    const ActParams none = make_act(0, 0.f, 0.f, 0, nullptr);
+    const int blocks = colsum_blocks(N);
+    colsum_fused_kernel<false><<<blocks, 256, 0, stream>>>(x, ld, nullptr, nullptr, N, C, none, workspace);
     QOT_LAUNCH_CHECK();
     colsum_final_kernel<<<grid_for(C, 4), 256, 0, stream>>>(workspace, blocks, C, out);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_act_bwd_colsum(const float* grad_y, const float* y, float* grad_x, int64_t N, int C, float slope,
+                                  float p, uint64_t seed, const int64_t* step_counter, float* colsum_out,
+                                  float* workspace, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || !grad_y || !y || !grad_x || !colsum_out || !workspace) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
+    const ActParams ap = make_act(1, slope, p, seed, step_counter);
+    const int blocks = colsum_blocks(N);
+    colsum_fused_kernel<true><<<blocks, 256, 0, stream>>>(grad_y, C, y, grad_x, N, C, ap, workspace);
+    QOT_LAUNCH_CHECK();
+    colsum_final_kernel<<<grid_for(C, 4), 256, 0, stream>>>(workspace, blocks, C, colsum_out);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

@@ -74,35 +74,49 @@ __global__ __launch_bounds__(4 * H) void table_project_fwd_kernel(const float* _
 
 // blocks [0, 4H): weight + bias gradient of packed row c (= s*H + o):  gw[c, a] = sum_v gp[v, c] table[v, a]
 // blocks [4H, 4H + V): table gradient row v:                          gt[v, a] = sum_c gp[v, c] w_{s(c)}[o(c), a]
-// grads: gw [4H, H] | gb [4H]   (packed q|k|v|skip order)
+// grads: gw [4H, H] | gb [4H]   (packed q|k|v|skip order).  256 threads = H columns x PH phases of the
+// reduction index (the loops are pure latency otherwise), phases meet in LDS in a fixed order.
 template <int H>
-__global__ __launch_bounds__(H) void table_project_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ table,
-                                                              Proj4 p, float* __restrict__ gtable,
-                                                              float* __restrict__ gw, float* __restrict__ gb, int V) {
-    const int a = threadIdx.x;
+__global__ __launch_bounds__(256) void table_project_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ table,
+                                                                Proj4 p, float* __restrict__ gtable,
+                                                                float* __restrict__ gw, float* __restrict__ gb, int V) {
+    constexpr int PH = 256 / H;
+    __shared__ float red[256];
+    __shared__ float redb[256];
+    const int a = threadIdx.x % H, ph = threadIdx.x / H;
+    float acc = 0.f, sb = 0.f;
     if ((int)blockIdx.x < 4 * H) {
         const int c = blockIdx.x;
-        float acc = 0.f, sb = 0.f;
-        for (int v = 0; v < V; ++v) {
+#pragma unroll 4
+        for (int v = ph; v < V; v += PH) {
             const float g = gp[(int64_t)v * 4 * H + c];
             acc = fmaf(g, table[(int64_t)v * H + a], acc);
             sb += g;
         }
-        gw[(int64_t)c * H + a] = acc;
-        if (a == 0) gb[c] = sb;
+        red[threadIdx.x] = acc;
+        redb[threadIdx.x] = sb;
+        __syncthreads();
+        if (ph == 0) {
+            for (int k = 1; k < PH; ++k) { acc += red[k * H + a]; sb += redb[k * H + a]; }
+            gw[(int64_t)c * H + a] = acc;
+            if (a == 0) gb[c] = sb;
+        }
     } else {
         const int v = blockIdx.x - 4 * H;
         __shared__ float g[4 * H];
-        for (int c = a; c < 4 * H; c += H) g[c] = gp[(int64_t)v * 4 * H + c];
+        for (int c = threadIdx.x; c < 4 * H; c += 256) g[c] = gp[(int64_t)v * 4 * H + c];
         __syncthreads();
-        float acc = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float* w = p.w[s];
-#pragma unroll 8
-            for (int o = 0; o < H; ++o) acc = fmaf(g[s * H + o], w[(int64_t)o * H + a], acc);
+#pragma unroll 4
+        for (int c = ph; c < 4 * H; c += PH) {
+            const int s = c / H, o = c % H;
+            acc = fmaf(g[c], p.w[s][(int64_t)o * H + a], acc);
         }
-        gtable[(int64_t)v * H + a] = acc;
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (ph == 0) {
+            for (int k = 1; k < PH; ++k) acc += red[k * H + a];
+            gtable[(int64_t)v * H + a] = acc;
+        }
     }
 }
 
@@ -163,7 +177,7 @@ extern "C" int qot_table_project_bwd(const float* grad_out, const float* table, 
     if (V <= 0) return QOT_ERR_BADARG;
     if (!grad_out || !table || !wq || !wk || !wv || !ws || !grad_table || !grad_w || !grad_b) return QOT_ERR_BADARG;
     Proj4 p{{wq, wk, wv, ws}, {nullptr, nullptr, nullptr, nullptr}};
-    QOT_TABLE_H(H, table_project_bwd_kernel<kH><<<4 * kH + V, kH, 0, (hipStream_t)stream>>>(
+    QOT_TABLE_H(H, table_project_bwd_kernel<kH><<<4 * kH + V, 256, 0, (hipStream_t)stream>>>(
                        grad_out, table, p, grad_table, grad_w, grad_b, V));
     QOT_LAUNCH_CHECK();
     return QOT_OK;

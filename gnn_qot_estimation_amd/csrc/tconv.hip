@@ -128,18 +128,41 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq,
     float* __restrict__ gskip, int ld_g, float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
-    int64_t N) {
+    int64_t N, const float* __restrict__ y_act, ActParams act, float* __restrict__ wedge_partials) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
+    __shared__ float wred[RPB * H * D];
     const int sub = threadIdx.x % TPR;
-    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
-    if (i >= N) return;
-    const float rs = rsqrtf((float)H);
+    const int rloc = threadIdx.x / TPR;
+    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + rloc;
     const int c0 = 4 * sub;
+    // rows past N (last block) contribute zeros to the block reduction below; no thread leaves
+    // before the barrier (a wave can hold live and dead rows)
+    float wc[4][D];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wc[c][d] = 0.f;
+    if (i < N) {
+    const float rs = rsqrtf((float)H);
     const int64_t ri = rowmap ? (int64_t)rowmap[i] : i;
 
     float4 qi = scale4(rs, ld4(q + ri * ld + c0));
     float4 gi = ld4(g + i * H + c0);
+    if (y_act) {      // grad_out arrives for y = dropout(leaky_relu(conv)): go back through it here
+        const int64_t flat = i * H + c0;
+        const float4 yy = ld4(y_act + flat);
+        uint64_t z = 0;
+        if (act.thr16) z = act_hash64(act.seed, (uint64_t)act.step[0], (uint64_t)flat >> 2);
+        float vi[4] = {gi.x, gi.y, gi.z, gi.w};
+        const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool keep = act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= act.thr16) : true;
+            vi[c] = vi[c] * (keep ? act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : act.slope);
+        }
+        gi = make_float4(vi[0], vi[1], vi[2], vi[3]);
+    }
     float wl[4][D];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -241,13 +264,33 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
             pal[i * D + d] = p2[d];
         }
     }
+    // grad of lin_edge.weight: gWe[c,d] += q_i[c]/sqrt(H) * pd_i[d] + g_i[c] * p2_i[d]
+    const float qc[4] = {qi.x, qi.y, qi.z, qi.w}, gc[4] = {gi.x, gi.y, gi.z, gi.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wc[c][d] = fmaf(qc[c], pd[d], gc[c] * p2[d]);
+    }   // i < N
+    if (wedge_partials) {
+        // rows of the block meet in LDS, blocks in qot_tconv_bwd_dst's final fixed-order sum
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) wred[rloc * H * D + (c0 + c) * D + d] = wc[c][d];
+        __syncthreads();
+        for (int o = threadIdx.x; o < H * D; o += 256) {
+            float sacc = 0.f;
+            for (int r = 0; r < RPB; ++r) sacc += wred[r * H * D + o];
+            wedge_partials[(int64_t)blockIdx.x * H * D + o] = sacc;
+        }
+    }
 }
 
 // Backward, source pass over the CSC: grad_v_j = sum_{e: j->i} a_e g_i,
 // grad_k_j = sum_e ds_e q_i / sqrt(H).
 template <int H>
 __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
-    const float* __restrict__ g, const float* __restrict__ q, int ld,
+    const float* __restrict__ g, int ld_go, const float* __restrict__ q, int ld,
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
     const int32_t* __restrict__ pos_t, const int32_t* __restrict__ qmap_t, float* __restrict__ gk,
@@ -281,7 +324,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
                 const int64_t i = __shfl(myi, u0 + u, TPR);
                 const int64_t iq = __shfl(myq, u0 + u, TPR);
                 const bool live = u0 + u < cnt;
-                gr[u] = ld4(g + (live ? i : 0) * H + c0);
+                gr[u] = ld4(g + (live ? i : 0) * ld_go + c0);
                 qr[u] = ld4(q + (live ? iq : 0) * ld + c0);
             }
 #pragma unroll
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
 // phase)), partials[blk, H*D] are then summed in a fixed order by the last kernel.
 template <int H, int D>
 __global__ __launch_bounds__(256) void tconv_wedge_partial_kernel(
-    const float* __restrict__ q, int ld, const int32_t* __restrict__ rowmap, const float* __restrict__ g,
+    const float* __restrict__ q, int ld, const int32_t* __restrict__ rowmap, const float* __restrict__ g, int ld_go,
     const float* __restrict__ pds, const float* __restrict__ pal, float* __restrict__ partials, int64_t N) {
     constexpr int PH = 256 / H;                 // row phases per block
     __shared__ float red[256 * D];
@@ -317,7 +360,7 @@ __global__ __launch_bounds__(256) void tconv_wedge_partial_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     for (int64_t i = r0 + ph; i < r1; i += PH) {
-        const float qv = q[(rowmap ? (int64_t)rowmap[i] : i) * ld + c] * rs, gv = g[i * H + c];
+        const float qv = q[(rowmap ? (int64_t)rowmap[i] : i) * ld + c] * rs, gv = g[i * ld_go + c];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = fmaf(qv, pds[i * D + d], fmaf(gv, pal[i * D + d], acc[d]));
     }
@@ -341,7 +384,19 @@ __global__ void partial_sum_kernel(const float* __restrict__ partials, int nblk,
     if ((threadIdx.x & 63) == 0) out[t] = s;
 }
 
+// out[g*n + t] = sum of partials[b*n + t] over the blocks b of group g (one wave per output)
+__global__ void partial_sum_groups_kernel(const float* __restrict__ partials, int nblk, int n, int per_group,
+                                          float* __restrict__ out) {
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const int b0 = blockIdx.y * per_group;
+    const int cnt = (b0 + per_group <= nblk) ? per_group : nblk - b0;
+    const float s = wave_sum_partials(partials + (int64_t)b0 * n, cnt, n, t);
+    if ((threadIdx.x & 63) == 0) out[(int64_t)blockIdx.y * n + t] = s;
+}
+
 constexpr int kWedgeBlocks = 512;
+constexpr int kWedgeGroup = 128;
 
 }  // namespace qot
 
@@ -359,7 +414,7 @@ extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowma
     int blocks = kWedgeBlocks;
     if (N < blocks * 8) blocks = (int)((N + 7) / 8);
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
-        tconv_wedge_partial_kernel<kH, kD><<<blocks, 256, 0, stream>>>(q, ld, rowmap, grad_out, pds, pal, workspace, N);
+        tconv_wedge_partial_kernel<kH, kD><<<blocks, 256, 0, stream>>>(q, ld, rowmap, grad_out, H, pds, pal, workspace, N);
     }));
     QOT_LAUNCH_CHECK();
     partial_sum_kernel<<<grid_for(H * D, 4), 256, 0, stream>>>(workspace, blocks, H * D, grad_w_edge);
@@ -389,33 +444,63 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
                                  int ld, const float* edge_attr, const float* w_edge,
                                  const float* stats, const int32_t* rowptr, const int32_t* col,
                                  const int32_t* eid, const int32_t* rowmap, float* grad_q, float* grad_skip,
-                                 int ld_g, float* escr, float* delta, float* pds, float* pal, int64_t N, int H, int D,
-                                 qot_stream_t stream) {
+                                 int ld_g, float* escr, float* delta, float* pds, float* pal,
+                                 const float* y_act, float act_slope, float act_p, uint64_t act_seed,
+                                 const int64_t* act_step, float* grad_w_edge, float* workspace,
+                                 int64_t N, int H, int D, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!grad_out || !q || !k || !v || !stats || !grad_q || !delta || !pds || !pal || (ld & 3) || (ld_g & 3))
         return QOT_ERR_BADARG;
+    if (grad_w_edge && !workspace) return QOT_ERR_BADARG;
+    const ActParams ap = make_act(y_act ? 1 : 0, act_slope, act_p, act_seed, act_step);
+    int blocks = 0;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
-        tconv_bwd_dst_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
+        blocks = grid_for(N, RPB);
+        tconv_bwd_dst_kernel<kH, kD><<<blocks, 256, 0, stream>>>(
             grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, grad_skip, ld_g, escr,
-            delta, pds, pal, N);
+            delta, pds, pal, N, y_act, ap, grad_w_edge ? workspace : nullptr);
     }));
     QOT_LAUNCH_CHECK();
+    if (grad_w_edge) {
+        const int n = H * D;
+        if (blocks > 2 * kWedgeGroup) {       // two levels: groups of kWedgeGroup blocks, then the groups
+            const int groups = grid_for(blocks, kWedgeGroup);
+            float* level1 = workspace + (size_t)blocks * n;
+            partial_sum_groups_kernel<<<dim3(grid_for(n, 4), groups), 256, 0, stream>>>(workspace, blocks, n,
+                                                                                      kWedgeGroup, level1);
+            QOT_LAUNCH_CHECK();
+            partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(level1, groups, n, grad_w_edge);
+        } else {
+            partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, blocks, n, grad_w_edge);
+        }
+        QOT_LAUNCH_CHECK();
+    }
     return QOT_OK;
 }
 
-extern "C" int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
+// floats of workspace qot_tconv_bwd_dst needs when grad_w_edge is requested
+extern "C" size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D) {
+    if (N <= 0 || H < 4 || D <= 0) return 0;
+    const int64_t rpb = 256 / (H / 4) > 0 ? 256 / (H / 4) : 1;
+    const int64_t blocks = (N + rpb - 1) / rpb;
+    const int64_t groups = (blocks + kWedgeGroup - 1) / kWedgeGroup;
+    return (size_t)(blocks + groups) * (size_t)H * (size_t)D;
+}
+
+extern "C" int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, const float* escr,
                                  const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
                                  const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
                                  int ld_g, int64_t N, int H, qot_stream_t stream) {
     if (N < 0 || !rowptr_t) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
-    if (!grad_out || !q || !delta || !grad_k || !grad_v || (ld & 3) || (ld_g & 3)) return QOT_ERR_BADARG;
+    if (!grad_out || !q || !delta || !grad_k || !grad_v || (ld & 3) || (ld_g & 3) || (ld_go & 3)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, {
         constexpr int RPB = 256 / (kH / 4);
         tconv_bwd_src_kernel<kH><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            grad_out, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N);
+            grad_out, ld_go, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -84,6 +84,22 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def act_backward_colsum(g, y, act):
+    """``(g', g'.sum(0))`` with ``g' = _act_backward(g, y, act)`` in one launch."""
+    slope, p, seed, step = act
+    g = _f32c(g)
+    n, c = g.shape
+    if n == 0 or c % 4 or c > 1024:
+        gx = _act_backward(g, y, act)
+        return gx, gx.sum(0)
+    gx = torch.empty_like(g)
+    out = torch.empty(c, dtype=torch.float32, device=g.device)
+    ws = torch.empty(_lib.load().qot_colsum_workspace_floats(c), dtype=torch.float32, device=g.device)
+    _lib.call("qot_act_bwd_colsum", P(g), P(y), P(gx), n, c, float(slope), float(p if step is not None else 0.0),
+              int(seed), P(step), P(out), P(ws))
+    return gx, out
+
+
 # ------------------------------------------------------------------ node-level Linear
 class LinearFn(torch.autograd.Function):
     """``x @ W^T + b`` over the node matrix.  Forward / grad_x are library GEMMs (MFMA); the
@@ -240,8 +256,6 @@ class TConvFn(torch.autograd.Function):
         qkvs, edge_attr, w_edge, stats, y, act_step = ctx.saved_tensors
         graph, maps = ctx.graph, ctx.maps
         g = _f32c(g)
-        if ctx.act is not None:          # fused leaky_relu + dropout: back through it first
-            g = _act_backward(g, y, ctx.act + (act_step,))
         H4 = qkvs.shape[1]
         H = H4 // 4
         D = w_edge.shape[1]
@@ -253,15 +267,22 @@ class TConvFn(torch.autograd.Function):
         delta = torch.empty(N, dtype=torch.float32, device=dev)
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
+        gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_tconv_bwd_dst_workspace_floats(N, H, D), dtype=torch.float32, device=dev)
+        # one launch: back through the fused leaky_relu+dropout (mask regenerated), destination pass,
+        # and the lin_edge weight gradient; gskip then holds the gradient wrt the conv output
+        if ctx.act is not None:
+            slope, p, seed = ctx.act
+            act_args = (P(y), float(slope), float(p if act_step is not None else 0.0), int(seed), P(act_step))
+        else:
+            act_args = (None, 0.0, 0.0, 0, None)
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
                   P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap),
-                  _off(gnode, 0), _off(gnode, 3 * H), H4, P(escr), P(delta), P(pds), P(pal), N, H, D)
-        _lib.call("qot_tconv_bwd_src", P(g), _off(qkvs, 0), H4, P(escr), P(delta), P(graph.rowptr_t),
-                  P(graph.col_t), P(graph.pos_t), P(colf_t), _off(gnode, H), _off(gnode, 2 * H), H4, N, H)
-        gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
-        ws = torch.empty(_lib.load().qot_tconv_wedge_workspace_floats(H, D), dtype=torch.float32, device=dev)
-        _lib.call("qot_tconv_wedge_grad", _off(qkvs, 0), H4, P(rowmap), P(g), P(pds), P(pal), P(gwe), P(ws),
-                  N, H, D)
+                  _off(gnode, 0), _off(gnode, 3 * H), H4, P(escr), P(delta), P(pds), P(pal), *act_args,
+                  P(gwe), P(ws), N, H, D)
+        _lib.call("qot_tconv_bwd_src", _off(gnode, 3 * H), H4, _off(qkvs, 0), H4, P(escr), P(delta),
+                  P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), P(colf_t), _off(gnode, H), _off(gnode, 2 * H),
+                  H4, N, H)
         if maps is None:
             gq = gnode
         else:
@@ -413,12 +434,13 @@ class NNConvFn(torch.autograd.Function):
         graph = ctx.graph
         g = _f32c(g)
         if ctx.act is not None:
-            g = _act_backward(g, y, ctx.act + (act_step,))
+            g, gbias = act_backward_colsum(g, y, ctx.act + (act_step,))
+        else:
+            gbias = colsum(g)
         N, hin = x.shape
         hout = wroot.shape[0]
         K, D = w1.shape
         dev = x.device
-        gbias = colsum(g)
         fused_all = _fused_ok(hin, hout) and D <= 4 and wp_adj is not None and not os.environ.get("QOT_SPLIT_NNCONV_BWD")
         wcat_t = None if fused_all else nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
         if fused_all:

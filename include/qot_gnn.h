@@ -104,17 +104,27 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
                   float* stats, int64_t N, int H, int D, int act, float act_slope, float act_p,
                   uint64_t act_seed, const int64_t* act_step, qot_stream_t stream);
-/* bwd, destination pass: grad_q[N,H] (ld_g), grad_skip[N,H] (= grad_out, same ld_g; may be NULL), per-edge scratch escr[cap,2] = (alpha, dalpha),
- * delta[N], pds[N,D] = sum_e ds_e ea_e, pal[N,D] = sum_e alpha_e ea_e. */
+/* bwd, destination pass: grad_q[N,H] (ld_g), grad_skip[N,H] (= grad wrt the conv output, same ld_g;
+ * may be NULL), per-edge scratch escr[cap,2] = (alpha, dalpha), delta[N], pds[N,D] = sum_e ds_e ea_e,
+ * pal[N,D] = sum_e alpha_e ea_e.
+ * y_act != NULL: grad_out is the gradient wrt y = dropout(leaky_relu(conv)) (the epilogue qot_tconv_fwd
+ * fused, models.py:54-55) and y_act is that output; the kernel goes back through the activation
+ * itself, so grad_skip then holds the gradient wrt the conv output -- pass IT (ld_go = ld_g) to
+ * qot_tconv_bwd_src.  grad_w_edge != NULL: grad of lin_edge.weight [H,D] is produced as well
+ * (fixed-order block partials; workspace qot_tconv_bwd_dst_workspace_floats(N,H,D) floats),
+ * replacing qot_tconv_wedge_grad. */
+size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D);
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,
                       const int32_t* rowptr, const int32_t* col, const int32_t* eid,
                       const int32_t* rowmap, float* grad_q, float* grad_skip, int ld_g, float* escr,
-                      float* delta,
-                      float* pds, float* pal, int64_t N, int H, int D, qot_stream_t stream);
+                      float* delta, float* pds, float* pal, const float* y_act, float act_slope, float act_p,
+                      uint64_t act_seed, const int64_t* act_step, float* grad_w_edge, float* workspace,
+                      int64_t N, int H, int D, qot_stream_t stream);
 /* bwd, source pass: grad_k, grad_v [N,H] (ld_g).  qmap_t (table mode, else NULL): table row of
- * each out-edge's destination (node_ids[col_t]) for the q gather; grad_out/delta stay per node. */
-int qot_tconv_bwd_src(const float* grad_out, const float* q, int ld, const float* escr,
+ * each out-edge's destination (node_ids[col_t]) for the q gather; grad_out (row stride ld_go) and
+ * delta stay per node. */
+int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, const float* escr,
                       const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
                       const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
                       int ld_g, int64_t N, int H, qot_stream_t stream);
@@ -248,7 +258,10 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
  * qot_small_gemm: C[M,N] = op(A) op(B) (+bias) with element strides (head MLP, table projection:
  * topological_training/models.py:33-38,63; a few MFLOP each).  split_k > 1: C holds split_k partial
  * planes [M, ldc] (K chunks of ceil(K/split_k) rounded to 32), summed by the caller in a fixed order.
- * qot_colsum: out[C] = column sums of x[N, C] (bias gradients), deterministic two-stage. */
+ * qot_colsum: out[C] = column sums of x[N, C] (bias gradients), deterministic two-stage.
+ * qot_act_bwd_colsum: grad_x = qot_act_bwd(grad_y, y) AND colsum(grad_x) in the same pass (bias
+ * gradient of a conv whose epilogue carried leaky_relu+dropout, models.py:54-58).
+ * Both take qot_colsum_workspace_floats(C) floats of workspace. */
 int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                      float momentum, int first_step, qot_stream_t stream);
 int qot_small_gemm(const float* A, int64_t stride_am, int64_t stride_ak, const float* B, int64_t stride_bk,
@@ -260,6 +273,9 @@ size_t qot_colsum_workspace_floats(int C);
 size_t qot_rowsum_wide_workspace_floats(int64_t C);
 int qot_rowsum_wide(const float* x, int64_t B, int64_t C, float* out, float* workspace, qot_stream_t stream);
 int qot_colsum(const float* x, int ld, int64_t N, int C, float* out, float* workspace, qot_stream_t stream);
+int qot_act_bwd_colsum(const float* grad_y, const float* y, float* grad_x, int64_t N, int C, float slope, float p,
+                       uint64_t seed, const int64_t* step_counter, float* colsum_out, float* workspace,
+                       qot_stream_t stream);
 
 /* ---- fused read-out head: global_mean_pool -> Linear(H,H) -> LeakyReLU -> Dropout -> Linear(H,O)
  * (topological_training/models.py:33-38,61-63).  fwd saves pooled[B,H] and hidden[B,H] (post dropout).
