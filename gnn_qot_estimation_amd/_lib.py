@@ -82,6 +82,8 @@ SIGNATURES = {
     "qot_smooth_l1": (_int, [_p, _p, _i64, _f, _p, _p, _p, _p]),
     "qot_table_project_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
     "qot_table_project_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
+    "qot_table_maps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "qot_step_advance": (_int, [_p, _p, _p]),
     "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),

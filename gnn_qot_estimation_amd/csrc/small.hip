@@ -130,9 +130,48 @@ __global__ void gather3_kernel(const float* __restrict__ s0, int n0, const float
     out[i] = v < n0 ? s0[v] : (v < n0 + n1 ? s1[v - n0] : s2[v - n0 - n1]);
 }
 
+// ---- table-mode index maps in one launch: ids32 = (int) node_ids ; colf = ids[col] ; colf_t = ids[col_t]
+__global__ void table_maps_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ col,
+                                  const int32_t* __restrict__ col_t, int32_t* __restrict__ ids32,
+                                  int32_t* __restrict__ colf, int32_t* __restrict__ colf_t, int64_t N, int64_t E) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < N) ids32[t] = (int32_t)ids[t];
+    if (t < E) {
+        colf[t] = (int32_t)ids[col[t]];
+        colf_t[t] = (int32_t)ids[col_t[t]];
+    }
+}
+
+// ---- dropout step counter: counter += 1 ; snapshot = counter (the draw backward re-reads) ------
+__global__ void step_advance_kernel(int64_t* __restrict__ counter, int64_t* __restrict__ snapshot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t c = counter[0] + 1;
+        counter[0] = c;
+        snapshot[0] = c;
+    }
+}
+
 }  // namespace qot
 
 using namespace qot;
+
+extern "C" int qot_table_maps(const int64_t* node_ids, const int32_t* col, const int32_t* col_t, int32_t* ids32,
+                              int32_t* colf, int32_t* colf_t, int64_t N, int64_t E, qot_stream_t stream) {
+    if (N < 0 || E < 0) return QOT_ERR_BADARG;
+    if (N == 0 && E == 0) return QOT_OK;
+    if (!node_ids || !ids32 || (E > 0 && (!col || !col_t || !colf || !colf_t))) return QOT_ERR_BADARG;
+    const int64_t n = N > E ? N : E;
+    table_maps_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(node_ids, col, col_t, ids32, colf, colf_t, N, E);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_step_advance(int64_t* counter, int64_t* snapshot, qot_stream_t stream) {
+    if (!counter || !snapshot) return QOT_ERR_BADARG;
+    step_advance_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, snapshot);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
 
 extern "C" size_t qot_smooth_l1_workspace_floats(void) { return 1024 + 1; }
 

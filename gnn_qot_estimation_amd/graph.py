@@ -130,6 +130,25 @@ def batch_index_for(data, num_nodes: int):
     return res
 
 
+def batch_ptr_for(data, num_nodes: int):
+    """(ptr32 [B+1], B): graph boundaries for the pooled read-out.  A batch object that carries
+    ``ptr`` (ours and PyG's do) only needs it narrowed to int32; otherwise it is derived from
+    ``batch`` as in ``batch_index_for``."""
+    ptr = getattr(data, "ptr", None)
+    B = getattr(data, "num_graphs", None)
+    if ptr is None or B is None or ptr.numel() != int(B) + 1 or not ptr.is_cuda:
+        _, p32, B = batch_index_for(data, num_nodes)
+        return p32, B
+    tag = (ptr.data_ptr(), ptr._version, tuple(ptr.shape))
+    c = _cache(data)
+    if c is not None and "ptr32" in c and c["ptr32"][0] == tag:
+        return c["ptr32"][1]
+    res = (to_i32(ptr), int(B))
+    if c is not None:
+        c["ptr32"] = (tag, res)
+    return res
+
+
 def cached_i32(data, name: str) -> torch.Tensor:
     t = getattr(data, name)
     tag = (t.data_ptr(), t._version, tuple(t.shape))
@@ -143,13 +162,14 @@ def cached_i32(data, name: str) -> torch.Tensor:
     return out
 
 
-def table_maps_for(data, graph: GraphIndex, ids32: torch.Tensor):
+def table_maps_for(data, graph: GraphIndex):
     """(rowmap, colf, colf_t, (B, n)) for TransformerConv's table mode, or None.
 
     Table mode needs ``node_ids == arange(n)`` repeated for every graph (what the reference's
     dataset emits: ``topological_training/dataset.py:78``) -- then the gradient of the projected
     table is a plain sum over graphs.  The batch object advertises it as ``uniform_node_ids = n``
     (set by ``Batch.from_data_list`` on the host); otherwise the general per-node path runs.
+    One launch builds the int32 node ids and both gathered column maps.
     """
     n = getattr(data, "uniform_node_ids", None)
     if not n:
@@ -157,15 +177,22 @@ def table_maps_for(data, graph: GraphIndex, ids32: torch.Tensor):
     N = graph.num_nodes
     if N % n != 0:
         return None
-    tag = (ids32.data_ptr(), graph.col.data_ptr())
+    ids = data.node_ids
+    tag = (ids.data_ptr(), ids._version, graph.col.data_ptr())
     c = _cache(data)
     if c is not None and "tmaps" in c and c["tmaps"][0] == tag:
         return c["tmaps"][1]
+    require_cuda(ids)
+    if ids.dtype != torch.int64:
+        ids = ids.long()
+    ids = ids.contiguous()
     E = graph.num_edges_in            # table mode is used without GAT self loops: every slot is live
-    colf = torch.empty(max(E, 1), dtype=torch.int32, device=ids32.device)
-    colf_t = torch.empty(max(E, 1), dtype=torch.int32, device=ids32.device)
-    _lib.call("qot_i32_gather", _lib.ptr(ids32), _lib.ptr(graph.col), _lib.ptr(colf), E)
-    _lib.call("qot_i32_gather", _lib.ptr(ids32), _lib.ptr(graph.col_t), _lib.ptr(colf_t), E)
+    dev = ids.device
+    ids32 = torch.empty(N, dtype=torch.int32, device=dev)
+    colf = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    colf_t = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    _lib.call("qot_table_maps", _lib.ptr(ids), _lib.ptr(graph.col), _lib.ptr(graph.col_t), _lib.ptr(ids32),
+              _lib.ptr(colf), _lib.ptr(colf_t), N, E)
     res = (ids32, colf, colf_t, (N // n, int(n)))
     if c is not None:
         c["tmaps"] = (tag, res)

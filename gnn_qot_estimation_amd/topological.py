@@ -14,8 +14,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import functional as QF
-from .graph import batch_index_for, cached_i32, graph_index_for, table_maps_for
+from . import _lib, functional as QF
+from .graph import batch_index_for, batch_ptr_for, cached_i32, graph_index_for, table_maps_for
 from .nn import NNConv, TransformerConv
 
 
@@ -60,24 +60,22 @@ class TopologicalGNN(nn.Module):
         if x is None or x.numel() == 0:
             n = data.node_ids.shape[0]
             graph = graph_index_for(data, n)
-            ids32 = cached_i32(data, "node_ids")
-            maps = table_maps_for(data, graph, ids32)
+            maps = table_maps_for(data, graph)
             if maps is None:
-                x = QF.EmbedFn.apply(self.node_embeddings.weight, ids32)
+                x = QF.EmbedFn.apply(self.node_embeddings.weight, cached_i32(data, "node_ids"))
         else:
             n = x.shape[0]
             graph = graph_index_for(data, n)
         step = None
         if self.training and self.dropout.p > 0.0:
-            self._qot_step.add_(1)
-            step = self._qot_step.clone()   # this forward's draw; backward re-reads the clone
+            step = torch.empty_like(self._qot_step)      # this forward's draw; backward re-reads it
+            _lib.call("qot_step_advance", _lib.ptr(self._qot_step), _lib.ptr(step))
         if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
             x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step))
         else:
             x = self.conv1(x, edge_index, edge_attr, graph=graph, act=self._act(0, step))
         for layer in range(2, self.num_layers + 1):
             x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=self._act(layer - 1, step))
-        b32, ptr, B = batch_index_for(data, n)
         l0, l3 = self.mlp[0], self.mlp[3]
         if x.shape[1] in (16, 32, 64, 128) and l3.out_features <= 8 and l0.out_features == x.shape[1]:
             # pool + head MLP (models.py:61-63) fused: one kernel forward, one backward
@@ -86,7 +84,9 @@ class TopologicalGNN(nn.Module):
                 self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
             seed = (self._qot_seed + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
             act = (self.mlp[1].negative_slope, p, seed, step if p > 0.0 else None)
+            ptr, B = batch_ptr_for(data, n)
             return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act)
+        b32, ptr, B = batch_index_for(data, n)
         x = QF.PoolFn.apply(x, b32, ptr, B)
         return self._head(x)
 

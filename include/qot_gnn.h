@@ -309,6 +309,14 @@ int qot_table_project_bwd(const float* grad_out, const float* table, const float
                           const float* wv, const float* ws, float* grad_table, float* grad_w, float* grad_b, int V,
                           int H, qot_stream_t stream);
 
+/* ---- TransformerConv table mode index maps in one launch (x = node_embeddings(node_ids),
+ * topological_training/models.py:51): ids32[N] = node_ids, colf[E] = node_ids[col],
+ * colf_t[E] = node_ids[col_t]. */
+int qot_table_maps(const int64_t* node_ids, const int32_t* col, const int32_t* col_t, int32_t* ids32,
+                   int32_t* colf, int32_t* colf_t, int64_t N, int64_t E, qot_stream_t stream);
+/* ---- dropout draw counter: *counter += 1 and *snapshot = *counter, on the stream (replay-safe). */
+int qot_step_advance(int64_t* counter, int64_t* snapshot, qot_stream_t stream);
+
 /* ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]]: one gather builds the fragment-ordered NNConv
  * operands from nn.2.weight / nn.2.bias / lin.weight (topological_training/models.py:20-25). */
 int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const float* s2, const int32_t* idx,
