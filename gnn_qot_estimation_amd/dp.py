@@ -70,7 +70,9 @@ class FlatModel:
     def all_reduce_grads(self, weight: Optional[torch.Tensor] = None, group=None):
         """Average gradients over ranks.  ``weight`` (0-dim tensor, e.g. the local number of
         loss rows) gives a weighted mean: needed where shards contribute different counts
-        (LightpathGNN: n_lut differs per shard, cf. lightpath_training/train.py:133)."""
+        (LightpathGNN: n_lut differs per shard, cf. lightpath_training/train.py:133).  Weighting after
+        backward is exact only when ranks are independent inside backward; with synchronised
+        BatchNorm statistics scale the local loss with ``loss_scale`` instead and average plainly."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         world = dist.get_world_size(group)
@@ -105,6 +107,22 @@ class FusedSGD:
         _lib.call("qot_sgd_momentum", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
                   _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, int(self.steps == 0))
         self.steps += 1
+
+
+def loss_scale(n_local: int, device, group=None) -> torch.Tensor:
+    """Factor that turns ``mean over the local loss rows`` into this rank's share of the mean over the
+    GLOBAL rows when gradients are afterwards averaged over ranks: ``n_local * world / sum(n_local)``.
+
+    Scaling the local loss BEFORE backward (instead of weighting gradients after it) is what stays
+    exact when ranks are coupled inside the backward pass (synchronised BatchNorm statistics,
+    ``functional.BnFn``): every rank then backpropagates its share of the same global loss.  One scalar
+    all-reduce; returns 1 without ``torch.distributed``."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return torch.ones((), dtype=torch.float32, device=device)
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    tot = t.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    return (t * dist.get_world_size(group) / tot.clamp_min(1.0)).float().reshape(())
 
 
 def graph_range(num_graphs: int, rank: int, world: int):

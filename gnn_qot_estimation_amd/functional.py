@@ -622,20 +622,54 @@ class GatFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)
+def _dist_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size()
+    return None, 1
+
+
 class BnFn(torch.autograd.Function):
     """BatchNorm1d over the node matrix with an optional fused ReLU.
 
     Training: batch statistics + in-place running-stat update (momentum, unbiased var).
     Eval: running statistics.  App. B.4.
+
+    ``sync``: under ``torch.distributed`` (one process per GPU) the batch statistics are
+    those of the GLOBAL batch, as in the single-process reference: forward all-reduces
+    ``(n*mean, n*E[x^2], n)`` (one ``[2C+1]`` fp64 message), backward all-reduces ``(sum dy*xhat, sum dy)``
+    (``[2C]``).  The parameter gradients returned stay local sums; the flat-gradient all-reduce
+    averages them like every other parameter.
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, sync=False):
         require_cuda(x, weight, bias)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         N, C = x.shape
         dev = x.device
-        if training:
+        dist, world = _dist_world() if (sync and training) else (None, 1)
+        n_tot = None
+        if training and world > 1:
+            mean_l = torch.zeros(C, dtype=torch.float32, device=dev)
+            rstd_l = torch.ones(C, dtype=torch.float32, device=dev)
+            if N > 0:
+                part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+                _lib.call("qot_bn_stats", P(x), N, C, float(eps), 0.0, P(mean_l), P(rstd_l), None, None, P(part))
+            m64 = mean_l.double()
+            ex2 = (1.0 / rstd_l.double().square() - eps).clamp_min(0.0) + m64 * m64 if N > 0 else m64 * 0.0
+            buf = torch.cat([m64 * N, ex2 * N, torch.tensor([float(N)], dtype=torch.float64, device=dev)])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            n_tot = buf[-1].clamp_min(1.0)       # (no host read: an all-empty global batch normalises nothing)
+            mean64 = buf[:C] / n_tot
+            var64 = (buf[C:2 * C] / n_tot - mean64 * mean64).clamp_min(0.0)
+            mean = mean64.float()
+            rstd = torch.rsqrt(var64 + eps).float()
+            with torch.no_grad():
+                unbiased = var64 * (n_tot / (n_tot - 1).clamp_min(1.0))
+                running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(unbiased.float(), alpha=momentum)
+        elif training:
             if N == 0:
                 raise ValueError("BatchNorm in training mode needs at least one row")
             mean = torch.empty(C, dtype=torch.float32, device=dev)
@@ -647,30 +681,39 @@ class BnFn(torch.autograd.Function):
             mean = running_mean.detach().to(torch.float32).contiguous()
             rstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
         y = torch.empty_like(x)
-        _lib.call("qot_bn_apply", P(x), P(mean), P(rstd), P(weight), P(bias), P(y), N, C, int(relu))
-        ctx.save_for_backward(x, y, mean, rstd, weight)
-        ctx.cfg = (bool(training), bool(relu))
+        if N > 0:
+            _lib.call("qot_bn_apply", P(x), P(mean), P(rstd), P(weight), P(bias), P(y), N, C, int(relu))
+        ctx.save_for_backward(x, y, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0))
+        ctx.cfg = (bool(training), bool(relu), world > 1)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, mean, rstd, weight = ctx.saved_tensors
-        training, relu = ctx.cfg
+        x, y, mean, rstd, weight, n_tot = ctx.saved_tensors
+        training, relu, synced = ctx.cfg
         g = _f32c(g)
         N, C = x.shape
         dev = x.device
-        gw = torch.empty(C, dtype=torch.float32, device=dev)
-        gb = torch.empty(C, dtype=torch.float32, device=dev)
+        gw = torch.zeros(C, dtype=torch.float32, device=dev)
+        gb = torch.zeros(C, dtype=torch.float32, device=dev)
         gx = torch.empty_like(x)
         if N > 0:
             part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
             _lib.call("qot_bn_bwd_reduce", P(g), P(y), P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
                       P(part))
-            _lib.call("qot_bn_bwd_apply", P(g), P(y), P(x), P(mean), P(rstd), P(weight), P(gw), P(gb), P(gx),
+        gw_use, gb_use = gw, gb
+        if synced:
+            dist, _ = _dist_world()
+            tot = torch.cat([gw, gb]).double()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            # the kernel divides by the LOCAL row count: pre-scale the global sums by N_local / n_total
+            scale = float(N) / n_tot
+            gw_use = (tot[:C] * scale).float().contiguous()
+            gb_use = (tot[C:] * scale).float().contiguous()
+        if N > 0:
+            _lib.call("qot_bn_bwd_apply", P(g), P(y), P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
                       N, C, int(relu), int(training))
-        else:
-            gw.zero_(); gb.zero_()
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ LUT rows (a9)

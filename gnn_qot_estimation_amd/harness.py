@@ -27,7 +27,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-from .dp import FlatModel, FusedSGD, graph_range
+from .dp import FlatModel, FusedSGD, graph_range, loss_scale
 from .loader import GraphLoader
 
 # data constants of the reference's label scaling (constants.py:8-12), used at test.py:95-99
@@ -172,18 +172,28 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
         for data in loader:
             if training:
                 flat.zero_grad()
+            if world > 1 and kind == "lightpath":
+                # ranks are coupled inside forward/backward (global BatchNorm statistics): a batch
+                # is skipped by all ranks or by none (one flag all-reduce, one host read per batch)
+                lut_col = getattr(model, "is_lut_index", None)
+                has = (data.x[:, lut_col] == 1.0).any().to(torch.int32).reshape(1)
+                dist.all_reduce(has, op=dist.ReduceOp.MIN)
+                if int(has.item()) == 0:
+                    skipped += data.num_graphs
+                    continue
             try:
                 out, y = fwd(model, data, out_dim)
             except ValueError:
                 skipped += data.num_graphs          # lightpath_training/train.py:118-121
-                if training and world > 1:          # keep the collective count equal on every rank
-                    flat.all_reduce_grads(weight=torch.zeros((), device=device))
                 continue
             loss = criterion(out, y)
             if training:
-                loss.backward()
                 if world > 1:
-                    flat.all_reduce_grads(weight=torch.tensor(float(y.shape[0]), device=device))
+                    # this rank's share of the global mean loss, then a plain average of gradients
+                    (loss * loss_scale(y.shape[0], device)).backward()
+                    flat.all_reduce_grads()
+                else:
+                    loss.backward()
                 opt.step()
             stats.update(y, out, loss)
     stats.all_reduce()

@@ -158,13 +158,15 @@ class BatchNorm(nn.Module):
         if not affine or not track_running_stats or momentum is None:
             raise NotImplementedError("only affine BatchNorm with running statistics")
         self.module = nn.BatchNorm1d(in_channels, eps=eps, momentum=momentum)
+        # one process per GPU: statistics over the global batch, as in the single-process reference
+        self.sync_stats = True
 
     def forward(self, x, relu: bool = False):
         m = self.module
         if self.training:
             m.num_batches_tracked.add_(1)
         return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
-                             m.momentum, m.eps, relu)
+                             m.momentum, m.eps, relu, self.sync_stats)
 
 
 def global_mean_pool(x, batch, size: Optional[int] = None, data=None):

@@ -1,0 +1,97 @@
+"""Data-parallel path with the HIP models: two processes (gloo rendezvous, both on cuda:0) each take a
+contiguous graph range; gradients after the flat all-reduce -- and, for LightpathGNN, the synchronised
+BatchNorm statistics -- must equal the single-process step on the whole batch.
+RCCL itself only runs on the multi-GPU node; everything else of the N > 1 path is exercised here."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(kind, dev):
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    torch.manual_seed(0)
+    if kind == "topo":
+        full = S.topological_batch(2, 8, n=20, e=60)
+        model = q.TopologicalGNN(20, 64, 3, 4, dropout_p=0.0)
+    else:
+        full = S.lightpath_batch(9)              # 4 + 5 graphs: unequal LUT counts per shard
+        model = q.LightpathGNN(5, 8, 3, 1, dropout_p=0.0)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1 and p.abs().max() == 0:
+                p.uniform_(-0.1, 0.1)
+    return full, model.to(dev).train()
+
+
+def _worker(rank, world, port, kind, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_qot_estimation_amd.batch import shard_graphs
+        from gnn_qot_estimation_amd.dp import FlatModel, loss_scale
+        dev = torch.device("cuda:0")
+        full, model = _build(kind, dev)
+        if rank == 1:                            # parameters must come from rank 0
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        flat = FlatModel(model)
+        flat.broadcast_params()
+        shard = shard_graphs(full, rank, world).to(dev)
+        flat.zero_grad()
+        if kind == "topo":
+            y = shard.y.view(-1, 3)
+            loss = F.smooth_l1_loss(model(shard), y)
+        else:
+            out, lb = model(shard)
+            y = shard.y[lb]
+            loss = F.smooth_l1_loss(out, y)
+        (loss * loss_scale(y.shape[0], dev)).backward()
+        flat.all_reduce_grads()
+        torch.cuda.synchronize()
+        if rank == 0:
+            ret["grad"] = flat.flat_grad.cpu()
+            ret["param"] = flat.flat_param.cpu()
+            if kind == "lightpath":
+                ret["rm"] = model.norm1.module.running_mean.cpu()
+                ret["rv"] = model.norm1.module.running_var.cpu()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["topo", "lightpath"])
+def test_two_rank_hip_step_matches_single_process(kind):
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+        got = dict(ret)
+    from gnn_qot_estimation_amd.dp import FlatModel
+    dev = torch.device("cuda:0")
+    full, model = _build(kind, dev)
+    flat = FlatModel(model)
+    assert torch.equal(got["param"], flat.flat_param.cpu())       # broadcast from rank 0
+    full = full.to(dev)
+    flat.zero_grad()
+    if kind == "topo":
+        F.smooth_l1_loss(model(full), full.y.view(-1, 3)).backward()
+    else:
+        out, lb = model(full)
+        F.smooth_l1_loss(out, full.y[lb]).backward()
+        assert rel_err(got["rm"], model.norm1.module.running_mean.cpu()) < 1e-5
+        assert rel_err(got["rv"], model.norm1.module.running_var.cpu()) < 1e-5
+    assert rel_err(got["grad"], flat.flat_grad.cpu()) < 2e-5
