@@ -323,7 +323,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 2-layer TopologicalGNN (TransformerConv+NNConv) hidden=64, "
                                    "100-node/400-directed-edge topologies, batch=1024 graphs per GPU, dropout 0.5, "
-                                   "SGD momentum 0.9, SmoothL1; CSR build included in every step",
+                                   "SGD momentum 0.9, SmoothL1; " + ("graph index cached across steps (BENCH_PREP_OUTSIDE: the HBM-resident, cached-batch loader mode; not the headline)" if os.environ.get("BENCH_PREP_OUTSIDE") else "CSR build included in every step"),
                        "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world,
                        "launch": "eager" if step.graph_fb is None else "hip-graph replay (fwd+bwd, optimizer)",
                        "parallelism": f"dp{world}", "final_loss": loss},

@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 from .dp import FlatModel, FusedSGD, graph_range, loss_scale
-from .loader import GraphLoader
+from .loader import GraphLoader, PackedGraphs
 
 # data constants of the reference's label scaling (constants.py:8-12), used at test.py:95-99
 TARGET_RANGES = {
@@ -162,8 +162,11 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     fwd = _KINDS[kind]
     rank, world = _rank_world()
     local_bs = max(1, batch_size // world)
+    # an HBM-resident shard keeps its batch objects (and the graph index the model attaches to them):
+    # the chunks repeat every few epochs, so later visits do no graph preparation at all
+    resident = isinstance(dataset, PackedGraphs) and dataset.device is not None
     loader = GraphLoader(dataset, local_bs, shuffle=False, device=device,
-                         indices=_local_indices(indices, batch_size, rank, world))
+                         indices=_local_indices(indices, batch_size, rank, world), cache_batches=resident)
     stats = RegressionStats(out_dim, device)
     skipped = 0
     training = opt is not None

@@ -128,6 +128,7 @@ class PackedGraphs:
         self.uniform_node_ids = uniform_node_ids
         self.y_rows = 0 if y is None else y.shape[0] // max(len(self), 1)
         self.pinned = False
+        self.device = None          # set by to_device(): the shard lives in HBM
 
     def __len__(self):
         return self.node_ptr.numel() - 1
@@ -145,6 +146,48 @@ class PackedGraphs:
                 setattr(self, name, t.contiguous().pin_memory())
         self.pinned = True
         return self
+
+    # ---- HBM-resident shard -------------------------------------------------------------------
+    def to_device(self, device="cuda") -> "PackedGraphs":
+        """Keep the WHOLE shard in device memory (the reference's 1.5 M-graph dataset is < 10 GB as
+        flat tensors; an MI355X has 288 GB).  ``GraphLoader`` then hands out batches that are views /
+        one-kernel re-basings of it -- no host collate, no H2D copy, no staging -- and, with
+        ``cache_batches=True``, keeps every batch object (and the graph index the model attaches to
+        it) for the following epochs: the reference trains 35 epochs over fixed, unshuffled chunks
+        (``train.py:79-95``), so from the second visit a step does no graph preparation at all."""
+        dev = torch.device(device)
+        out = PackedGraphs(self.node_ptr, self.edge_ptr,
+                           self.edge_index.to(dev), None if self.edge_attr is None else self.edge_attr.to(dev),
+                           None if self.node_ids is None else self.node_ids.to(dev),
+                           None if self.x is None else self.x.to(dev), None if self.y is None else self.y.to(dev),
+                           self.uniform_node_ids)
+        sizes = (self.node_ptr[1:] - self.node_ptr[:-1])
+        out.graph_of_node = torch.repeat_interleave(torch.arange(len(self)), sizes).to(dev)
+        out.node_ptr_dev = self.node_ptr.to(dev)
+        out.device = dev
+        out._batch_cache = {}
+        return out
+
+    def device_batch(self, lo: int, hi: int, cache: bool = False) -> Batch:
+        """Graphs [lo, hi) of a device-resident shard as a ``Batch`` (three small kernels, or none
+        when the batch object is cached)."""
+        if cache and (lo, hi) in self._batch_cache:
+            return self._batch_cache[(lo, hi)]
+        n0, n1 = int(self.node_ptr[lo]), int(self.node_ptr[hi])
+        e0, e1 = int(self.edge_ptr[lo]), int(self.edge_ptr[hi])
+        out = Batch()
+        out.num_graphs, out._num_nodes = hi - lo, n1 - n0
+        out.uniform_node_ids = self.uniform_node_ids
+        out.edge_index = self.edge_index[:, e0:e1] - n0 if n0 else self.edge_index[:, e0:e1]
+        out.edge_attr = None if self.edge_attr is None else self.edge_attr[e0:e1]
+        out.node_ids = None if self.node_ids is None else self.node_ids[n0:n1]
+        out.x = None if self.x is None else self.x[n0:n1]
+        out.y = None if self.y is None else self.y[lo * self.y_rows:hi * self.y_rows]
+        out.ptr = self.node_ptr_dev[lo:hi + 1] - n0
+        out.batch = self.graph_of_node[n0:n1] - lo
+        if cache:
+            self._batch_cache[(lo, hi)] = out
+        return out
 
     def __getitem__(self, g: int) -> Data:
         n0, n1 = int(self.node_ptr[g]), int(self.node_ptr[g + 1])
@@ -205,7 +248,7 @@ class GraphLoader:
 
     def __init__(self, dataset: Sequence[Data], batch_size: int, shuffle: bool = False, drop_last: bool = False,
                  device="cuda", depth: int = 2, generator: Optional[torch.Generator] = None,
-                 indices: Optional[Sequence[int]] = None):
+                 indices: Optional[Sequence[int]] = None, cache_batches: bool = False):
         """``indices`` restricts the loader to a subset of ``dataset`` (the role of
         ``torch.utils.data.Subset`` at ``topological_training/train.py:34-36,89``) without wrapping
         it, so a pinned ``PackedGraphs`` keeps its zero-collate path for consecutive ranges."""
@@ -215,6 +258,7 @@ class GraphLoader:
         self.device = torch.device(device)
         self.generator = generator
         self.indices = None if indices is None else list(indices)
+        self.cache_batches = cache_batches
         self.cuda = self.device.type == "cuda"
         self.depth = max(2, depth) if self.cuda else 1
         self._stages = [_Staging(self.device, pin=True) for _ in range(self.depth)] if self.cuda else []
@@ -271,6 +315,12 @@ class GraphLoader:
         chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
         if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
             chunks.pop()
+        resident = isinstance(self.dataset, PackedGraphs) and self.dataset.device is not None
+        if resident and all(list(c) == list(range(c[0], c[0] + len(c))) for c in chunks):
+            # HBM-resident shard, consecutive graphs: batches are views of it (nothing to stage)
+            for c in chunks:
+                yield self.dataset.device_batch(c[0], c[0] + len(c), cache=self.cache_batches)
+            return
         if not self.cuda:
             for c in chunks:
                 yield self._stage(c, 0)

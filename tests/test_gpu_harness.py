@@ -78,3 +78,28 @@ def test_fit_lightpath_skips_batches_without_lut():
     assert np.isfinite(hist.loss).all()
     res = Hn.evaluate(model, graphs, kind="lightpath", batch_size=4)
     assert set(res) == {"OSNR", "SNR", "BER"}
+
+
+def test_hbm_resident_shard_batches_and_cache():
+    """``PackedGraphs.to_device``: batches are views of the resident shard, equal to the collated ones;
+    with ``cache_batches`` the same batch object (graph index attached) comes back on the next epoch."""
+    from gnn_qot_estimation_amd.loader import GraphLoader
+    graphs = _topological_dataset(50)
+    shard = q.PackedGraphs.from_data_list(graphs).to_device("cuda")
+    ld = GraphLoader(shard, batch_size=16, device="cuda", cache_batches=True)
+    first = list(ld)
+    assert [b.num_graphs for b in first] == [16, 16, 16, 2]
+    for k, b in enumerate(first):
+        ref = q.Batch.from_data_list(graphs[16 * k:16 * k + 16])
+        for name in ("edge_index", "edge_attr", "node_ids", "y", "batch", "ptr"):
+            assert torch.equal(getattr(b, name).cpu(), getattr(ref, name)), name
+        assert b.uniform_node_ids == 12
+    model = q.TopologicalGNN(num_nodes=12, hidden_channels=16, out_channels=3, edge_dim=4, dropout_p=0.0).cuda()
+    out0 = model(first[1])
+    again = list(ld)
+    assert all(a is b for a, b in zip(first, again))
+    assert "graph" in again[1]._qot_cache or len(again[1]._qot_cache) > 0      # index built once, kept
+    assert torch.equal(model(again[1]), out0)
+    # the training loop accepts the resident shard (fit -> run_epoch -> cached batches)
+    hist = Hn.fit(model, shard, kind="topological", batch_size=8, num_epochs=3, chunk_fraction=0.5, log=lambda s: None)
+    assert hist.epochs_run == 3 and np.isfinite(hist.loss).all()
