@@ -205,7 +205,8 @@ def kernel_table(model, batch):
                                            P(g.rowptr_t), P(g.col_t), P(g.pos_t), None, off(gq, H), off(gq, 2 * H),
                                            4 * H, N, H),
         2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)
-    add("csr_build", lambda: build_graph_index(batch.edge_index, N), 16 * E + 8 * 4 * E + 3 * 4 * N)
+    slices = (batch.ptr, batch.edge_ptr) + tuple(batch.graph_sizes) if getattr(batch, "edge_ptr", None) is not None else None
+    add("csr_build", lambda: build_graph_index(batch.edge_index, N, slices=slices), 16 * E + 8 * 4 * E + 3 * 4 * N)
     return rows
 
 

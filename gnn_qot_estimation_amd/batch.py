@@ -18,7 +18,7 @@ import torch
 class Data:
     """One graph (or, as ``Batch``, many).  Plain attribute bag."""
 
-    _TENSOR_FIELDS = ("x", "edge_index", "edge_attr", "y", "node_ids", "batch", "ptr")
+    _TENSOR_FIELDS = ("x", "edge_index", "edge_attr", "y", "node_ids", "batch", "ptr", "edge_ptr")
 
     def __init__(self, x=None, edge_index=None, edge_attr=None, y=None, node_ids=None, num_nodes=None):
         self.x = x
@@ -28,6 +28,8 @@ class Data:
         self.node_ids = node_ids
         self.batch = None
         self.ptr = None
+        self.edge_ptr = None        # Batch: per-graph edge offsets [B+1]; graph_sizes: (max nodes, max edges)
+        self.graph_sizes = None
         self._num_nodes = num_nodes
 
     @property
@@ -94,6 +96,11 @@ class Batch(Data):
         out.y = cat("y")
         eis = [g.edge_index + off for g, off in zip(graphs, offsets[:-1])]
         out.edge_index = torch.cat(eis, dim=1) if eis else torch.zeros(2, 0, dtype=torch.long)
+        # per-graph edge slices (PyG keeps the same in Batch._slice_dict): with them the graph index of a
+        # block-diagonal batch is built by one workgroup per graph (qot_csr_build_by_graph)
+        ecounts = [g.num_edges for g in graphs]
+        out.edge_ptr = torch.tensor([0] + ecounts, dtype=torch.long).cumsum(0)
+        out.graph_sizes = (max(sizes, default=0), max(ecounts, default=0))
         return out
 
 
@@ -116,6 +123,10 @@ def shard_graphs(batch: Batch, rank: int, world: int) -> Batch:
     keep = (ei[1] >= n0) & (ei[1] < n1)
     out.edge_index = ei[:, keep] - n0
     out.edge_attr = None if batch.edge_attr is None else batch.edge_attr[keep]
+    ep = getattr(batch, "edge_ptr", None)
+    if ep is not None and bool(keep[int(ep[lo]):int(ep[hi])].all()) and int(keep.sum()) == int(ep[hi] - ep[lo]):
+        out.edge_ptr = ep[lo:hi + 1] - ep[lo]
+        out.graph_sizes = getattr(batch, "graph_sizes", None)
     if batch.y is not None:
         per = batch.y.shape[0] // max(b, 1)
         out.y = batch.y[lo * per:hi * per]

@@ -104,6 +104,110 @@ __global__ void csc_pos_kernel(int32_t* __restrict__ pos_t, const int32_t* __res
     if (t < (int64_t)rowptr_t[N]) pos_t[t] = slot_of[pos_t[t]];
 }
 
+// ---- block-diagonal batches: the whole index in ONE launch, one workgroup per graph ----------
+// A collated batch keeps every graph's nodes AND edges contiguous (PyG keeps the same slices), so
+// graph b's CSR/CSC slots are exactly [edge_ptr[b], edge_ptr[b+1]): histogram, scan, placement, the
+// per-row ordering by edge id and the CSC mapping all happen in that workgroup's LDS -- no global
+// atomics, no cross-workgroup scan, no workspace.  Same output as the general path (same order).
+// LDS ints: cin[n] cout[n] rp[n+1] rpt[n+1] | rank_in[m] rank_out[m] key_in[m] key_out[m] slot_of[m]
+// status (optional): bit 0 set if an edge leaves its graph's node range (caller's slices are wrong).
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total);
+
+__device__ __forceinline__ void block_scan_into(const int* __restrict__ cnt, int* __restrict__ out, int n) {
+    // exclusive scan of cnt[0..n) into out[0..n], out[n] = total; all 256 threads call it
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int idx = c0 + threadIdx.x;
+        const int v = idx < n ? cnt[idx] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, &total);
+        const int carry = carry_s;
+        if (idx < n) out[idx] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void csr_by_graph_kernel(
+    const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t B, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+    int32_t* __restrict__ eid, int32_t* __restrict__ row, int32_t* __restrict__ rowptr_t,
+    int32_t* __restrict__ col_t, int32_t* __restrict__ pos_t, int32_t* __restrict__ eid_t,
+    float* __restrict__ invdeg, int32_t* __restrict__ status, int cap_n, int cap_m) {
+    extern __shared__ int lds[];
+    const int64_t b = blockIdx.x;
+    const int64_t n0 = node_ptr[b], e0 = edge_ptr[b];
+    int n = (int)(node_ptr[b + 1] - n0), m = (int)(edge_ptr[b + 1] - e0);
+    if (n > cap_n || m > cap_m || n < 0 || m < 0) {      // host-side size bound violated: flag, do nothing
+        if (threadIdx.x == 0 && status) atomicOr(status, 2);
+        return;
+    }
+    int* cin = lds;
+    int* cout = cin + cap_n;
+    int* rp = cout + cap_n;
+    int* rpt = rp + cap_n + 1;
+    int* rank_in = rpt + cap_n + 1;
+    int* rank_out = rank_in + cap_m;
+    int* key_in = rank_out + cap_m;
+    int* key_out = key_in + cap_m;
+    int* slot_of = key_out + cap_m;
+    for (int t = threadIdx.x; t < n; t += 256) { cin[t] = 0; cout[t] = 0; }
+    __syncthreads();
+    bool bad = false;
+    for (int e = threadIdx.x; e < m; e += 256) {
+        int j = (int)(ei[e0 + e] - n0), i = (int)(ei[E + e0 + e] - n0);
+        if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
+        rank_in[e] = atomicAdd(&cin[i], 1);
+        rank_out[e] = atomicAdd(&cout[j], 1);
+    }
+    if (bad && status) atomicOr(status, 1);
+    __syncthreads();
+    block_scan_into(cin, rp, n);
+    block_scan_into(cout, rpt, n);
+    for (int e = threadIdx.x; e < m; e += 256) {
+        int j = (int)(ei[e0 + e] - n0), i = (int)(ei[E + e0 + e] - n0);
+        i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+        j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+        key_in[rp[i] + rank_in[e]] = e;
+        key_out[rpt[j] + rank_out[e]] = e;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < 2 * n; r += 256) {
+        if (r < n) {
+            const int beg = rp[r], end = rp[r + 1];
+            sort_row_keys(key_in, beg, end);
+            for (int p = beg; p < end; ++p) {
+                const int key = key_in[p];
+                col[e0 + p] = (int32_t)ei[e0 + key];
+                eid[e0 + p] = (int32_t)(e0 + key);
+                row[e0 + p] = (int32_t)(n0 + r);
+                slot_of[key] = p;
+            }
+            const int d = end - beg;
+            invdeg[n0 + r] = 1.0f / (float)(d > 1 ? d : 1);
+            rowptr[n0 + r] = (int32_t)(e0 + beg);
+        } else {
+            const int jj = r - n;
+            const int beg = rpt[jj], end = rpt[jj + 1];
+            sort_row_keys(key_out, beg, end);
+            for (int t = beg; t < end; ++t) {
+                const int key = key_out[t];
+                col_t[e0 + t] = (int32_t)ei[E + e0 + key];
+                eid_t[e0 + t] = (int32_t)(e0 + key);
+            }
+            rowptr_t[n0 + jj] = (int32_t)(e0 + beg);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < m; t += 256) pos_t[e0 + t] = (int32_t)(e0 + slot_of[key_out[t]]);
+    if (b == B - 1 && threadIdx.x == 0) { rowptr[N] = (int32_t)E; rowptr_t[N] = (int32_t)E; }
+}
+
 // ---- exclusive scan of two int32 arrays (in-degrees, out-degrees), plain kernels only --------
 // (the prep runs inside a captured HIP graph every step: no library calls, no memset nodes)
 constexpr int kScanChunk = 2048;        // elements per 256-thread block (8 per thread)
@@ -288,6 +392,36 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
                                                                invdeg, rowptr_t, key_out, col_t, eid_t);
     QOT_LAUNCH_CHECK();
     csc_pos_kernel<<<grid_for(cap, T), T, 0, stream>>>(pos_t, slot_of, rowptr_t, N);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// LDS bytes of csr_by_graph_kernel for graphs of at most max_nodes / max_edges
+static size_t by_graph_lds_bytes(int64_t max_nodes, int64_t max_edges) {
+    return (size_t)(4 * max_nodes + 2 + 5 * max_edges) * 4;
+}
+
+extern "C" int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
+                                      const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges,
+                                      int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
+                                      int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
+                                      float* invdeg, int32_t* status, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (E < 0 || N < 0 || B < 0 || max_nodes < 0 || max_edges < 0 || !rowptr || !rowptr_t || !invdeg) return QOT_ERR_BADARG;
+    if (N >= (int64_t(1) << 31) - 1 || E >= (int64_t(1) << 31) - 1) return QOT_ERR_UNSUPPORTED;
+    if (by_graph_lds_bytes(max_nodes, max_edges) > 64 * 1024) return QOT_ERR_UNSUPPORTED;   // use qot_csr_build
+    if (B == 0) {
+        if (N != 0 || E != 0) return QOT_ERR_BADARG;
+        zero_i32_kernel<<<1, 64, 0, stream>>>(rowptr, 1);
+        zero_i32_kernel<<<1, 64, 0, stream>>>(rowptr_t, 1);
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
+    if (!node_ptr || !edge_ptr || (E > 0 && (!edge_index || !col || !eid || !row || !col_t || !pos_t || !eid_t)))
+        return QOT_ERR_BADARG;
+    csr_by_graph_kernel<<<(int)B, 256, by_graph_lds_bytes(max_nodes, max_edges), stream>>>(
+        edge_index, E, N, node_ptr, edge_ptr, B, rowptr, col, eid, row, rowptr_t, col_t, pos_t, eid_t, invdeg, status,
+        (int)max_nodes, (int)max_edges);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

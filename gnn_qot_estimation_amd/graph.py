@@ -41,7 +41,11 @@ def require_cuda(*tensors):
             )
 
 
-def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False) -> GraphIndex:
+def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False,
+                      slices=None) -> GraphIndex:
+    """``slices = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 device tensors ``[B+1]`` and host
+    ints) marks a block-diagonal batch whose graphs keep nodes and edges contiguous: the index is then
+    built by one workgroup per graph in a single launch (``qot_csr_build_by_graph``)."""
     require_cuda(edge_index)
     if edge_index.dtype != torch.long or edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must be int64 [2, E]")
@@ -61,6 +65,17 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
         gat_self_loops=gat_self_loops,
     )
     lib = _lib.load()
+    if slices is not None and not gat_self_loops:
+        node_ptr, edge_ptr, max_n, max_m = slices
+        B = node_ptr.numel() - 1
+        if (B >= 1 and edge_ptr.numel() == B + 1 and node_ptr.is_cuda and edge_ptr.is_cuda
+                and node_ptr.dtype == torch.long and edge_ptr.dtype == torch.long
+                and (4 * int(max_n) + 2 + 5 * int(max_m)) * 4 <= 64 * 1024):
+            _lib.call("qot_csr_build_by_graph", _lib.ptr(ei), E, N, _lib.ptr(node_ptr.contiguous()),
+                      _lib.ptr(edge_ptr.contiguous()), B, int(max_n), int(max_m), _lib.ptr(g.rowptr), _lib.ptr(g.col),
+                      _lib.ptr(g.eid), _lib.ptr(g.row), _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t), _lib.ptr(g.pos_t),
+                      _lib.ptr(g.eid_t), _lib.ptr(g.invdeg), None)
+            return g
     ws_bytes = lib.qot_csr_workspace_bytes(E, N, int(gat_self_loops))
     if ws_bytes == 0:
         raise _lib.QotError("qot_csr_workspace_bytes failed")
@@ -90,7 +105,12 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> Graph
     c = _cache(data)
     if c is not None and key in c and c[key][0] == tag:
         return c[key][1]
-    g = build_graph_index(ei, num_nodes, gat_self_loops)
+    slices = None
+    ptr, eptr, sizes = getattr(data, "ptr", None), getattr(data, "edge_ptr", None), getattr(data, "graph_sizes", None)
+    if (not gat_self_loops and ptr is not None and eptr is not None and sizes is not None
+            and ptr.numel() == eptr.numel() and ptr.is_cuda and eptr.is_cuda):
+        slices = (ptr, eptr, sizes[0], sizes[1])
+    g = build_graph_index(ei, num_nodes, gat_self_loops, slices)
     if c is not None:
         c[key] = (tag, g)
     return g

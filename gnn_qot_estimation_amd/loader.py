@@ -26,7 +26,7 @@ import torch
 
 from .batch import Batch, Data
 
-_FIELDS = ("x", "edge_index", "edge_attr", "y", "node_ids", "batch", "ptr")
+_FIELDS = ("x", "edge_index", "edge_attr", "y", "node_ids", "batch", "ptr", "edge_ptr")
 
 
 class _Staging:
@@ -70,6 +70,8 @@ def collate_into(graphs: Sequence[Data], st: Optional[_Staging]) -> Batch:
     out = Batch()
     out.num_graphs, out._num_nodes = B, N
     ptr = st.host_view("ptr", (B + 1,), torch.long)
+    eptr = st.host_view("edge_ptr", (B + 1,), torch.long)
+    eptr[0] = 0
     batch = st.host_view("batch", (N,), torch.long)
     ei = st.host_view("edge_index", (2, E), torch.long)
     off = 0
@@ -94,7 +96,10 @@ def collate_into(graphs: Sequence[Data], st: Optional[_Staging]) -> Batch:
         off += n
         eo += e
         ptr[gi + 1] = off
+        eptr[gi + 1] = eo
     out.ptr, out.batch, out.edge_index = ptr, batch, ei
+    out.edge_ptr = eptr
+    out.graph_sizes = (max(sizes, default=0), max(edges, default=0))
     for name in ("x", "edge_attr", "node_ids", "y"):
         setattr(out, name, cat_fields[name][0] if name in cat_fields else None)
     out.uniform_node_ids = None
@@ -127,6 +132,8 @@ class PackedGraphs:
         self.edge_attr, self.node_ids, self.x, self.y = edge_attr, node_ids, x, y
         self.uniform_node_ids = uniform_node_ids
         self.y_rows = 0 if y is None else y.shape[0] // max(len(self), 1)
+        ncnt, ecnt = node_ptr[1:] - node_ptr[:-1], edge_ptr[1:] - edge_ptr[:-1]
+        self.graph_sizes = (int(ncnt.max()) if ncnt.numel() else 0, int(ecnt.max()) if ecnt.numel() else 0)
         self.pinned = False
         self.device = None          # set by to_device(): the shard lives in HBM
 
@@ -164,6 +171,7 @@ class PackedGraphs:
         sizes = (self.node_ptr[1:] - self.node_ptr[:-1])
         out.graph_of_node = torch.repeat_interleave(torch.arange(len(self)), sizes).to(dev)
         out.node_ptr_dev = self.node_ptr.to(dev)
+        out.edge_ptr_dev = self.edge_ptr.to(dev)
         out.device = dev
         out._batch_cache = {}
         return out
@@ -184,6 +192,8 @@ class PackedGraphs:
         out.x = None if self.x is None else self.x[n0:n1]
         out.y = None if self.y is None else self.y[lo * self.y_rows:hi * self.y_rows]
         out.ptr = self.node_ptr_dev[lo:hi + 1] - n0
+        out.edge_ptr = self.edge_ptr_dev[lo:hi + 1] - e0
+        out.graph_sizes = self.graph_sizes
         out.batch = self.graph_of_node[n0:n1] - lo
         if cache:
             self._batch_cache[(lo, hi)] = out
@@ -229,6 +239,12 @@ class PackedGraphs:
             if n0:
                 ptr.sub_(n0)
             out.ptr = ptr
+            eptr = st.dev_view("edge_ptr", (hi - lo + 1,), torch.long)
+            eptr.copy_(self.edge_ptr[lo:hi + 1], non_blocking=True)
+            if e0:
+                eptr.sub_(e0)
+            out.edge_ptr = eptr
+            out.graph_sizes = self.graph_sizes
             counts = ptr[1:] - ptr[:-1]
             bt = st.dev_view("batch", (n1 - n0,), torch.long)
             bt.copy_(torch.repeat_interleave(torch.arange(hi - lo, device=dev), counts, output_size=n1 - n0))
@@ -294,6 +310,7 @@ class GraphLoader:
         host = collate_into(graphs, st)
         dev = Batch()
         dev.num_graphs, dev._num_nodes, dev.uniform_node_ids = host.num_graphs, host._num_nodes, host.uniform_node_ids
+        dev.graph_sizes = host.graph_sizes
         # the device buffers of this slot were last read `depth` batches ago: the copy stream must
         # not overwrite them before that step's kernels are done
         self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))

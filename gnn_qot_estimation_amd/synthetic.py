@@ -134,4 +134,8 @@ def tile_batch(base: Batch, times: int) -> Batch:
     out.edge_index = torch.cat([base.edge_index + k * n for k in range(times)], dim=1)
     rep = lambda t: None if t is None else torch.cat([t] * times, dim=0)
     out.x, out.edge_attr, out.node_ids, out.y = rep(base.x), rep(base.edge_attr), rep(base.node_ids), rep(base.y)
+    if getattr(base, "edge_ptr", None) is not None:
+        e = base.num_edges
+        out.edge_ptr = torch.cat([base.edge_ptr[:-1] + k * e for k in range(times)] + [torch.tensor([e * times])])
+        out.graph_sizes = base.graph_sizes
     return out

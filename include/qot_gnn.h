@@ -71,6 +71,19 @@ int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_
                   int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
                   int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg,
                   void* workspace, size_t workspace_bytes, qot_stream_t stream);
+/* Same index for a BLOCK-DIAGONAL batch whose graphs keep their nodes and edges contiguous (what a
+ * collate produces; PyG's Batch keeps the same slices): node_ptr[B+1], edge_ptr[B+1] (int64, device)
+ * give graph b's node / edge ranges, max_nodes / max_edges bound the largest graph (host-known).
+ * One launch, one workgroup per graph, everything in LDS: no global atomics, no workspace.  Output
+ * identical to qot_csr_build(gat_self_loops = 0).  Returns QOT_ERR_UNSUPPORTED when the largest graph
+ * does not fit LDS ((4 max_nodes + 5 max_edges) * 4 bytes > 64 KB): use qot_csr_build then.
+ * status (optional, device int32, caller-zeroed): bit 0 = an edge leaves its graph's node range,
+ * bit 1 = a graph exceeds max_nodes / max_edges. */
+int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
+                           const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges,
+                           int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row, int32_t* rowptr_t,
+                           int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg, int32_t* status,
+                           qot_stream_t stream);
 /* out[i] = map[idx[i]] (int32): table row of every CSR / CSC slot's source / destination
  * (node_ids[col], node_ids[col_t]) for TransformerConv's table mode.  idx values must be < len(map). */
 int qot_i32_gather(const int32_t* map, const int32_t* idx, int32_t* out, int64_t n, qot_stream_t stream);

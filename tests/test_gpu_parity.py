@@ -423,3 +423,42 @@ def test_table_projection_matches_linear(H, V):
     want = torch.autograd.grad(ref, args, g)
     for a, b in zip(got, want):
         assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.gpu
+def test_csr_by_graph_equals_general_build(cuda_device):
+    """Block-diagonal batch: one workgroup per graph (LDS only) must emit exactly the general build's
+    index -- ragged graph sizes, an empty graph, shuffled edge order inside every graph."""
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    torch.manual_seed(0)
+    sizes = [7, 1, 300, 12, 0, 40, 33]
+    ecnt = [20, 0, 1500, 30, 0, 0, 64]
+    ptr = torch.tensor([0] + sizes).cumsum(0)
+    eptr = torch.tensor([0] + ecnt).cumsum(0)
+    parts = []
+    for n, m, off in zip(sizes, ecnt, ptr[:-1].tolist()):
+        if m:
+            parts.append(torch.randint(0, n, (2, m)) + off)
+    ei = torch.cat(parts, 1).to(cuda_device)
+    N, dev = int(ptr[-1]), cuda_device
+    a = build_graph_index(ei, N)
+    b = build_graph_index(ei, N, slices=(ptr.to(dev), eptr.to(dev), max(sizes), max(ecnt)))
+    for name in ("rowptr", "col", "eid", "row", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg"):
+        ta, tb = getattr(a, name), getattr(b, name)
+        m = ei.shape[1] if name not in ("rowptr", "rowptr_t", "invdeg") else ta.numel()
+        assert torch.equal(ta[:m], tb[:m]), name
+    # status flags: an edge that leaves its graph / a graph larger than the bound
+    from gnn_qot_estimation_amd import _lib
+    P = _lib.ptr
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad = ei.clone(); bad[0, 0] = N - 1
+    g = b
+    _lib.call("qot_csr_build_by_graph", P(bad), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), max(sizes),
+              max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
+              P(g.invdeg), P(st))
+    assert int(st.item()) & 1
+    st.zero_()
+    _lib.call("qot_csr_build_by_graph", P(ei), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), 100,
+              max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
+              P(g.invdeg), P(st))
+    assert int(st.item()) & 2
