@@ -31,7 +31,7 @@ SIGNATURES = {
     "qot_csr_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "qot_csr_build": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "qot_csr_build_by_graph": (_int, [_p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                      _p, _p]),
+                                      _p, _p, _p, _p, _p, _p, _p]),
     "qot_i32_gather": (_int, [_p, _p, _p, _i64, _p]),
     "qot_i64_to_i32": (_int, [_p, _p, _i64, _p]),
     "qot_batch_ptr": (_int, [_p, _i64, _i64, _p, _p]),

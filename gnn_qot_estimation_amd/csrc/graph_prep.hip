@@ -110,6 +110,7 @@ __global__ void csc_pos_kernel(int32_t* __restrict__ pos_t, const int32_t* __res
 // per-row ordering by edge id and the CSC mapping all happen in that workgroup's LDS -- no global
 // atomics, no cross-workgroup scan, no workspace.  Same output as the general path (same order).
 // LDS ints: cin[n] cout[n] rp[n+1] rpt[n+1] | rank_in[m] rank_out[m] key_in[m] key_out[m] slot_of[m]
+//           ends[m] (local source << 16 | local destination: the edge list is read from HBM once)
 // status (optional): bit 0 set if an edge leaves its graph's node range (caller's slices are wrong).
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total);
 
@@ -138,15 +139,23 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
     const int64_t* __restrict__ edge_ptr, int64_t B, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
     int32_t* __restrict__ eid, int32_t* __restrict__ row, int32_t* __restrict__ rowptr_t,
     int32_t* __restrict__ col_t, int32_t* __restrict__ pos_t, int32_t* __restrict__ eid_t,
-    float* __restrict__ invdeg, int32_t* __restrict__ status, int cap_n, int cap_m) {
+    float* __restrict__ invdeg, int32_t* __restrict__ status, int cap_n, int cap_m,
+    const int64_t* __restrict__ node_ids, int32_t* __restrict__ ids32, int32_t* __restrict__ colf,
+    int32_t* __restrict__ colf_t, int32_t* __restrict__ ptr32) {
     extern __shared__ int lds[];
     const int64_t b = blockIdx.x;
     const int64_t n0 = node_ptr[b], e0 = edge_ptr[b];
     int n = (int)(node_ptr[b + 1] - n0), m = (int)(edge_ptr[b + 1] - e0);
+    if (ptr32 && threadIdx.x == 0) {
+        ptr32[b] = (int32_t)n0;
+        if (b == B - 1) ptr32[B] = (int32_t)node_ptr[B];
+    }
     if (n > cap_n || m > cap_m || n < 0 || m < 0) {      // host-side size bound violated: flag, do nothing
         if (threadIdx.x == 0 && status) atomicOr(status, 2);
         return;
     }
+    if (node_ids)
+        for (int t = threadIdx.x; t < n; t += 256) ids32[n0 + t] = (int32_t)node_ids[n0 + t];
     int* cin = lds;
     int* cout = cin + cap_n;
     int* rp = cout + cap_n;
@@ -156,12 +165,14 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
     int* key_in = rank_out + cap_m;
     int* key_out = key_in + cap_m;
     int* slot_of = key_out + cap_m;
+    unsigned int* ends = reinterpret_cast<unsigned int*>(slot_of + cap_m);
     for (int t = threadIdx.x; t < n; t += 256) { cin[t] = 0; cout[t] = 0; }
     __syncthreads();
     bool bad = false;
     for (int e = threadIdx.x; e < m; e += 256) {
         int j = (int)(ei[e0 + e] - n0), i = (int)(ei[E + e0 + e] - n0);
         if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
+        ends[e] = ((unsigned int)j << 16) | (unsigned int)i;
         rank_in[e] = atomicAdd(&cin[i], 1);
         rank_out[e] = atomicAdd(&cout[j], 1);
     }
@@ -170,11 +181,9 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
     block_scan_into(cin, rp, n);
     block_scan_into(cout, rpt, n);
     for (int e = threadIdx.x; e < m; e += 256) {
-        int j = (int)(ei[e0 + e] - n0), i = (int)(ei[E + e0 + e] - n0);
-        i = i < 0 ? 0 : (i >= n ? n - 1 : i);
-        j = j < 0 ? 0 : (j >= n ? n - 1 : j);
-        key_in[rp[i] + rank_in[e]] = e;
-        key_out[rpt[j] + rank_out[e]] = e;
+        const unsigned int ji = ends[e];
+        key_in[rp[ji & 0xFFFFu] + rank_in[e]] = e;
+        key_out[rpt[ji >> 16] + rank_out[e]] = e;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < 2 * n; r += 256) {
@@ -183,7 +192,9 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
             sort_row_keys(key_in, beg, end);
             for (int p = beg; p < end; ++p) {
                 const int key = key_in[p];
-                col[e0 + p] = (int32_t)ei[e0 + key];
+                const int64_t src = n0 + (int64_t)(ends[key] >> 16);
+                col[e0 + p] = (int32_t)src;
+                if (node_ids) colf[e0 + p] = (int32_t)node_ids[src];
                 eid[e0 + p] = (int32_t)(e0 + key);
                 row[e0 + p] = (int32_t)(n0 + r);
                 slot_of[key] = p;
@@ -197,7 +208,9 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
             sort_row_keys(key_out, beg, end);
             for (int t = beg; t < end; ++t) {
                 const int key = key_out[t];
-                col_t[e0 + t] = (int32_t)ei[E + e0 + key];
+                const int64_t dst = n0 + (int64_t)(ends[key] & 0xFFFFu);
+                col_t[e0 + t] = (int32_t)dst;
+                if (node_ids) colf_t[e0 + t] = (int32_t)node_ids[dst];
                 eid_t[e0 + t] = (int32_t)(e0 + key);
             }
             rowptr_t[n0 + jj] = (int32_t)(e0 + beg);
@@ -398,18 +411,23 @@ extern "C" int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, in
 
 // LDS bytes of csr_by_graph_kernel for graphs of at most max_nodes / max_edges
 static size_t by_graph_lds_bytes(int64_t max_nodes, int64_t max_edges) {
-    return (size_t)(4 * max_nodes + 2 + 5 * max_edges) * 4;
+    return (size_t)(4 * max_nodes + 2 + 6 * max_edges) * 4;
 }
+constexpr size_t kByGraphLdsMax = 144 * 1024;     // one workgroup per CU at most
+constexpr int64_t kByGraphMaxNodes = 65535;       // local node ids are packed 16 + 16 bits
 
 extern "C" int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
                                       const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges,
                                       int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row,
                                       int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t, int32_t* eid_t,
-                                      float* invdeg, int32_t* status, qot_stream_t stream_) {
+                                      float* invdeg, int32_t* status, const int64_t* node_ids, int32_t* ids32,
+                                      int32_t* colf, int32_t* colf_t, int32_t* ptr32, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (node_ids && (!ids32 || (E > 0 && (!colf || !colf_t)))) return QOT_ERR_BADARG;
     if (E < 0 || N < 0 || B < 0 || max_nodes < 0 || max_edges < 0 || !rowptr || !rowptr_t || !invdeg) return QOT_ERR_BADARG;
     if (N >= (int64_t(1) << 31) - 1 || E >= (int64_t(1) << 31) - 1) return QOT_ERR_UNSUPPORTED;
-    if (by_graph_lds_bytes(max_nodes, max_edges) > 64 * 1024) return QOT_ERR_UNSUPPORTED;   // use qot_csr_build
+    if (max_nodes > kByGraphMaxNodes || by_graph_lds_bytes(max_nodes, max_edges) > kByGraphLdsMax)
+        return QOT_ERR_UNSUPPORTED;                                                      // use qot_csr_build
     if (B == 0) {
         if (N != 0 || E != 0) return QOT_ERR_BADARG;
         zero_i32_kernel<<<1, 64, 0, stream>>>(rowptr, 1);
@@ -419,9 +437,18 @@ extern "C" int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int6
     }
     if (!node_ptr || !edge_ptr || (E > 0 && (!edge_index || !col || !eid || !row || !col_t || !pos_t || !eid_t)))
         return QOT_ERR_BADARG;
+    {   // dynamic LDS above 64 KB has to be allowed once (the first call is outside any graph capture)
+        static size_t allowed = 64 * 1024;
+        const size_t need = by_graph_lds_bytes(max_nodes, max_edges);
+        if (need > allowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(csr_by_graph_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+            allowed = need;
+        }
+    }
     csr_by_graph_kernel<<<(int)B, 256, by_graph_lds_bytes(max_nodes, max_edges), stream>>>(
         edge_index, E, N, node_ptr, edge_ptr, B, rowptr, col, eid, row, rowptr_t, col_t, pos_t, eid_t, invdeg, status,
-        (int)max_nodes, (int)max_edges);
+        (int)max_nodes, (int)max_edges, node_ids, ids32, colf, colf_t, ptr32);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

@@ -30,6 +30,11 @@ class GraphIndex:
     eid_t: torch.Tensor    # [cap] int32 original edge id of each out-edge
     invdeg: torch.Tensor   # [N] fp32 1/max(in_degree,1)
     gat_self_loops: bool
+    # by-products of the one-launch build of block-diagonal batches (None otherwise)
+    ids32: Optional[torch.Tensor] = None    # [N] int32 node_ids
+    colf: Optional[torch.Tensor] = None     # [E] int32 node_ids[col]
+    colf_t: Optional[torch.Tensor] = None   # [E] int32 node_ids[col_t]
+    ptr32: Optional[torch.Tensor] = None    # [B+1] int32 graph boundaries
 
 
 def require_cuda(*tensors):
@@ -42,7 +47,7 @@ def require_cuda(*tensors):
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False,
-                      slices=None) -> GraphIndex:
+                      slices=None, node_ids: Optional[torch.Tensor] = None) -> GraphIndex:
     """``slices = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 device tensors ``[B+1]`` and host
     ints) marks a block-diagonal batch whose graphs keep nodes and edges contiguous: the index is then
     built by one workgroup per graph in a single launch (``qot_csr_build_by_graph``)."""
@@ -70,11 +75,18 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
         B = node_ptr.numel() - 1
         if (B >= 1 and edge_ptr.numel() == B + 1 and node_ptr.is_cuda and edge_ptr.is_cuda
                 and node_ptr.dtype == torch.long and edge_ptr.dtype == torch.long
-                and (4 * int(max_n) + 2 + 5 * int(max_m)) * 4 <= 64 * 1024):
+                and int(max_n) <= 65535 and (4 * int(max_n) + 2 + 6 * int(max_m)) * 4 <= 144 * 1024):
+            g.ptr32 = torch.empty(B + 1, **i32)
+            ids = None
+            if node_ids is not None and node_ids.is_cuda and node_ids.dtype == torch.long and node_ids.numel() == N:
+                ids = node_ids.contiguous()
+                g.ids32 = torch.empty(N, **i32)
+                g.colf, g.colf_t = torch.empty(max(E, 1), **i32), torch.empty(max(E, 1), **i32)
             _lib.call("qot_csr_build_by_graph", _lib.ptr(ei), E, N, _lib.ptr(node_ptr.contiguous()),
                       _lib.ptr(edge_ptr.contiguous()), B, int(max_n), int(max_m), _lib.ptr(g.rowptr), _lib.ptr(g.col),
                       _lib.ptr(g.eid), _lib.ptr(g.row), _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t), _lib.ptr(g.pos_t),
-                      _lib.ptr(g.eid_t), _lib.ptr(g.invdeg), None)
+                      _lib.ptr(g.eid_t), _lib.ptr(g.invdeg), None, _lib.ptr(ids), _lib.ptr(g.ids32), _lib.ptr(g.colf),
+                      _lib.ptr(g.colf_t), _lib.ptr(g.ptr32))
             return g
     ws_bytes = lib.qot_csr_workspace_bytes(E, N, int(gat_self_loops))
     if ws_bytes == 0:
@@ -110,9 +122,12 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> Graph
     if (not gat_self_loops and ptr is not None and eptr is not None and sizes is not None
             and ptr.numel() == eptr.numel() and ptr.is_cuda and eptr.is_cuda):
         slices = (ptr, eptr, sizes[0], sizes[1])
-    g = build_graph_index(ei, num_nodes, gat_self_loops, slices)
+    ids = getattr(data, "node_ids", None) if (slices is not None and getattr(data, "uniform_node_ids", None)) else None
+    g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids)
     if c is not None:
         c[key] = (tag, g)
+        if g.ptr32 is not None:       # read-out boundaries came with the index
+            c["ptr32"] = ((ptr.data_ptr(), ptr._version, tuple(ptr.shape)), (g.ptr32, ptr.numel() - 1))
     return g
 
 
@@ -202,6 +217,11 @@ def table_maps_for(data, graph: GraphIndex):
     c = _cache(data)
     if c is not None and "tmaps" in c and c["tmaps"][0] == tag:
         return c["tmaps"][1]
+    if graph.colf is not None and graph.ids32 is not None:      # built together with the index
+        res = (graph.ids32, graph.colf, graph.colf_t, (N // n, int(n)))
+        if c is not None:
+            c["tmaps"] = (tag, res)
+        return res
     require_cuda(ids)
     if ids.dtype != torch.int64:
         ids = ids.long()

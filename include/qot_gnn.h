@@ -76,13 +76,18 @@ int qot_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int gat_self_
  * give graph b's node / edge ranges, max_nodes / max_edges bound the largest graph (host-known).
  * One launch, one workgroup per graph, everything in LDS: no global atomics, no workspace.  Output
  * identical to qot_csr_build(gat_self_loops = 0).  Returns QOT_ERR_UNSUPPORTED when the largest graph
- * does not fit LDS ((4 max_nodes + 5 max_edges) * 4 bytes > 64 KB): use qot_csr_build then.
+ * does not fit LDS ((4 max_nodes + 6 max_edges) * 4 bytes > 144 KB, or max_nodes > 65535): use
+ * qot_csr_build then.
  * status (optional, device int32, caller-zeroed): bit 0 = an edge leaves its graph's node range,
- * bit 1 = a graph exceeds max_nodes / max_edges. */
+ * bit 1 = a graph exceeds max_nodes / max_edges.
+ * Optional by-products of the same pass (NULL to skip): with node_ids[N] (int64) the TransformerConv
+ * table-mode maps ids32[N] = node_ids, colf[E] = node_ids[col], colf_t[E] = node_ids[col_t]
+ * (qot_table_maps); ptr32[B+1] = node_ptr narrowed to int32 (read-out boundaries). */
 int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
                            const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges,
                            int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row, int32_t* rowptr_t,
                            int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg, int32_t* status,
+                           const int64_t* node_ids, int32_t* ids32, int32_t* colf, int32_t* colf_t, int32_t* ptr32,
                            qot_stream_t stream);
 /* out[i] = map[idx[i]] (int32): table row of every CSR / CSC slot's source / destination
  * (node_ids[col], node_ids[col_t]) for TransformerConv's table mode.  idx values must be < len(map). */

@@ -447,6 +447,11 @@ def test_csr_by_graph_equals_general_build(cuda_device):
         ta, tb = getattr(a, name), getattr(b, name)
         m = ei.shape[1] if name not in ("rowptr", "rowptr_t", "invdeg") else ta.numel()
         assert torch.equal(ta[:m], tb[:m]), name
+    ids = torch.randint(0, 50, (N,), device=dev)
+    c = build_graph_index(ei, N, slices=(ptr.to(dev), eptr.to(dev), max(sizes), max(ecnt)), node_ids=ids)
+    m = ei.shape[1]
+    assert torch.equal(c.ids32.long(), ids) and torch.equal(c.ptr32.long().cpu(), ptr)
+    assert torch.equal(c.colf[:m].long(), ids[a.col[:m].long()]) and torch.equal(c.colf_t[:m].long(), ids[a.col_t[:m].long()])
     # status flags: an edge that leaves its graph / a graph larger than the bound
     from gnn_qot_estimation_amd import _lib
     P = _lib.ptr
@@ -455,10 +460,10 @@ def test_csr_by_graph_equals_general_build(cuda_device):
     g = b
     _lib.call("qot_csr_build_by_graph", P(bad), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), max(sizes),
               max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
-              P(g.invdeg), P(st))
+              P(g.invdeg), P(st), None, None, None, None, None)
     assert int(st.item()) & 1
     st.zero_()
     _lib.call("qot_csr_build_by_graph", P(ei), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), 100,
               max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
-              P(g.invdeg), P(st))
+              P(g.invdeg), P(st), None, None, None, None, None)
     assert int(st.item()) & 2
