@@ -199,11 +199,11 @@ def kernel_table(model, batch):
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
                                            4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,
                                            off(gq, 0), off(gq, 3 * H), 4 * H, P(escr), P(delta), P(pds), P(pal),
-                                           None, 0.0, 0.0, 0, None, None, None, N, H, D),
+                                           None, 0.0, 0.0, 0, None, None, None, 0, 0, None, N, H, D),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 8 * E + 4 * N + 8 * N * D)
     add("tconv_bwd_src", lambda: _lib.call("qot_tconv_bwd_src", P(gout), H, off(qkvs, 0), 4 * H, P(escr), P(delta),
                                            P(g.rowptr_t), P(g.col_t), P(g.pos_t), None, off(gq, H), off(gq, 2 * H),
-                                           4 * H, N, H),
+                                           4 * H, 0, 0, None, N, H),
         2 * N * H * 4 + 2 * N * H * 4 + 8 * E + 4 * N + csr + 4 * E)
     slices = (batch.ptr, batch.edge_ptr) + tuple(batch.graph_sizes) if getattr(batch, "edge_ptr", None) is not None else None
     add("csr_build", lambda: build_graph_index(batch.edge_index, N, slices=slices), 16 * E + 8 * 4 * E + 3 * 4 * N)

@@ -128,13 +128,31 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq,
     float* __restrict__ gskip, int ld_g, float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
-    int64_t N, const float* __restrict__ y_act, ActParams act, float* __restrict__ wedge_partials) {
+    int64_t N, const float* __restrict__ y_act, ActParams act, float* __restrict__ wedge_partials,
+    int tile_n, int64_t tile_B, float* __restrict__ gpart) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
     __shared__ float wred[RPB * H * D];
+    __shared__ float4 tred[2][256];
     const int sub = threadIdx.x % TPR;
     const int rloc = threadIdx.x / TPR;
-    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + rloc;
+    // Row of this lane group.  Tile mode (table mode with node_ids == arange(n) per graph, gpart !=
+    // NULL): the workgroup takes node r of RPB consecutive graphs, so that the table gradient -- the
+    // sum over graphs -- is pre-reduced over those RPB rows in LDS instead of being written per node
+    // and re-read by a row-sum (4H floats per node each way).
+    int64_t i, prow = 0;
+    {
+        const int vb = xcd_block(blockIdx.x, gridDim.x);
+        if (gpart) {
+            const int gb = vb / tile_n, r = vb % tile_n;
+            const int64_t gph = (int64_t)gb * RPB + rloc;
+            i = gph < tile_B ? gph * tile_n + r : N;
+            prow = (int64_t)gb * tile_n + r;
+        } else {
+            i = (int64_t)vb * RPB + rloc;
+        }
+    }
+    float4 rq = f4zero(), rg = f4zero();
     const int c0 = 4 * sub;
     // rows past N (last block) contribute zeros to the block reduction below; no thread leaves
     // before the barrier (a wave can hold live and dead rows)
@@ -254,7 +272,9 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
         for (int d = 0; d < D; ++d) rc[c] = fmaf(wl[c][d], pd[d], rc[c]);
         rc[c] *= rs;
     }
-    st4(gq + i * ld_g + c0, make_float4(rc[0], rc[1], rc[2], rc[3]));
+    rq = make_float4(rc[0], rc[1], rc[2], rc[3]);
+    rg = gi;
+    if (!gpart) st4(gq + i * ld_g + c0, rq);
     if (gskip) st4(gskip + i * ld_g + c0, gi);        // grad of the skip projection is grad_out itself
     if (sub == 0) {
         delta[i] = sada;
@@ -284,6 +304,20 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
             wedge_partials[(int64_t)blockIdx.x * H * D + o] = sacc;
         }
     }
+    if (gpart) {       // rows of the RPB graphs meet in LDS (fixed order): one partial table row per workgroup
+        tred[0][threadIdx.x] = rq;
+        tred[1][threadIdx.x] = rg;
+        __syncthreads();
+        if (rloc == 0) {
+            float4 a = tred[0][sub], bsum = tred[1][sub];
+            for (int r2 = 1; r2 < RPB; ++r2) {
+                a = add4(a, tred[0][r2 * TPR + sub]);
+                bsum = add4(bsum, tred[1][r2 * TPR + sub]);
+            }
+            st4(gpart + prow * 4 * H + c0, a);
+            st4(gpart + prow * 4 * H + 3 * H + c0, bsum);
+        }
+    }
 }
 
 // Backward, source pass over the CSC: grad_v_j = sum_{e: j->i} a_e g_i,
@@ -294,16 +328,30 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
     const int32_t* __restrict__ pos_t, const int32_t* __restrict__ qmap_t, float* __restrict__ gk,
-    float* __restrict__ gv, int ld_g, int64_t N) {
+    float* __restrict__ gv, int ld_g, int64_t N, int tile_n, int64_t tile_B, float* __restrict__ gpart) {
     constexpr int TPR = H / 4;
     constexpr int RPB = 256 / TPR;
+    __shared__ float4 tred[2][256];
     const int sub = threadIdx.x % TPR;
-    const int64_t j = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
-    if (j >= N) return;
+    const int rloc = threadIdx.x / TPR;
+    int64_t j, prow = 0;
+    {
+        const int vb = xcd_block(blockIdx.x, gridDim.x);
+        if (gpart) {                                   // tile mode: see tconv_bwd_dst_kernel
+            const int gb = vb / tile_n, r = vb % tile_n;
+            const int64_t gph = (int64_t)gb * RPB + rloc;
+            j = gph < tile_B ? gph * tile_n + r : N;
+            prow = (int64_t)gb * tile_n + r;
+        } else {
+            j = (int64_t)vb * RPB + rloc;
+        }
+    }
+    if (j >= N && !gpart) return;
     const float rs = rsqrtf((float)H);
     const int c0 = 4 * sub;
     float4 ak = f4zero(), av = f4zero();
-    const int beg = rowptr_t[j], end = rowptr_t[j + 1];
+    int beg = 0, end = 0;
+    if (j < N) { beg = rowptr_t[j]; end = rowptr_t[j + 1]; }
     constexpr int BT = (TPR < 16) ? TPR : 16;
     for (int base = beg; base < end; base += BT) {
         const int tme = base + sub;
@@ -337,8 +385,23 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
             }
         }
     }
-    st4(gk + j * ld_g + c0, ak);
-    st4(gv + j * ld_g + c0, av);
+    if (!gpart) {
+        st4(gk + j * ld_g + c0, ak);
+        st4(gv + j * ld_g + c0, av);
+        return;
+    }
+    tred[0][threadIdx.x] = ak;
+    tred[1][threadIdx.x] = av;
+    __syncthreads();
+    if (rloc == 0) {
+        float4 a = tred[0][sub], bsum = tred[1][sub];
+        for (int r2 = 1; r2 < RPB; ++r2) {
+            a = add4(a, tred[0][r2 * TPR + sub]);
+            bsum = add4(bsum, tred[1][r2 * TPR + sub]);
+        }
+        st4(gpart + prow * 4 * H + H + c0, a);
+        st4(gpart + prow * 4 * H + 2 * H + c0, bsum);
+    }
 }
 
 // grad of lin_edge.weight [H, D]:  gWe[c,d] = sum_i ( q_i[c]/sqrt(H) * pds_i[d] + g_i[c] * pal_i[d] ).
@@ -447,21 +510,23 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
                                  int ld_g, float* escr, float* delta, float* pds, float* pal,
                                  const float* y_act, float act_slope, float act_p, uint64_t act_seed,
                                  const int64_t* act_step, float* grad_w_edge, float* workspace,
+                                 int tile_n, int64_t tile_B, float* grad_part,
                                  int64_t N, int H, int D, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
-    if (!grad_out || !q || !k || !v || !stats || !grad_q || !delta || !pds || !pal || (ld & 3) || (ld_g & 3))
+    if (!grad_out || !q || !k || !v || !stats || (!grad_q && !grad_part) || !delta || !pds || !pal || (ld & 3) || (ld_g & 3))
         return QOT_ERR_BADARG;
+    if (grad_part && (tile_n <= 0 || tile_B <= 0 || (int64_t)tile_n * tile_B != N || !rowmap)) return QOT_ERR_BADARG;
     if (grad_w_edge && !workspace) return QOT_ERR_BADARG;
     const ActParams ap = make_act(y_act ? 1 : 0, act_slope, act_p, act_seed, act_step);
     int blocks = 0;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
         constexpr int RPB = 256 / (kH / 4);
-        blocks = grid_for(N, RPB);
+        blocks = grad_part ? tile_n * grid_for(tile_B, RPB) : grid_for(N, RPB);
         tconv_bwd_dst_kernel<kH, kD><<<blocks, 256, 0, stream>>>(
             grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, grad_skip, ld_g, escr,
-            delta, pds, pal, N, y_act, ap, grad_w_edge ? workspace : nullptr);
+            delta, pds, pal, N, y_act, ap, grad_w_edge ? workspace : nullptr, tile_n, tile_B, grad_part);
     }));
     QOT_LAUNCH_CHECK();
     if (grad_w_edge) {
@@ -481,7 +546,8 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
     return QOT_OK;
 }
 
-// floats of workspace qot_tconv_bwd_dst needs when grad_w_edge is requested
+// floats of workspace qot_tconv_bwd_dst needs when grad_w_edge is requested (tile mode: pass
+// N = tile_n * ceil(tile_B / RPB) * RPB, RPB = 1024 / H)
 extern "C" size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D) {
     if (N <= 0 || H < 4 || D <= 0) return 0;
     const int64_t rpb = 256 / (H / 4) > 0 ? 256 / (H / 4) : 1;
@@ -493,14 +559,19 @@ extern "C" size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D) {
 extern "C" int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, const float* escr,
                                  const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
                                  const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
-                                 int ld_g, int64_t N, int H, qot_stream_t stream) {
+                                 int ld_g, int tile_n, int64_t tile_B, float* grad_part, int64_t N, int H,
+                                 qot_stream_t stream) {
     if (N < 0 || !rowptr_t) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
-    if (!grad_out || !q || !delta || !grad_k || !grad_v || (ld & 3) || (ld_g & 3) || (ld_go & 3)) return QOT_ERR_BADARG;
+    if (!grad_out || !q || !delta || ((!grad_k || !grad_v) && !grad_part) || (ld & 3) || (ld_g & 3) || (ld_go & 3))
+        return QOT_ERR_BADARG;
+    if (grad_part && (tile_n <= 0 || tile_B <= 0 || (int64_t)tile_n * tile_B != N)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, {
         constexpr int RPB = 256 / (kH / 4);
-        tconv_bwd_src_kernel<kH><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
-            grad_out, ld_go, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N);
+        const int blocks = grad_part ? tile_n * grid_for(tile_B, RPB) : grid_for(N, RPB);
+        tconv_bwd_src_kernel<kH><<<blocks, 256, 0, (hipStream_t)stream>>>(
+            grad_out, ld_go, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N, tile_n,
+            tile_B, grad_part);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -262,13 +262,28 @@ class TConvFn(torch.autograd.Function):
         N = graph.num_nodes
         dev = qkvs.device
         rowmap, colf, colf_t = (maps[0], maps[1], maps[2]) if maps is not None else (None, graph.col, None)
-        gnode = torch.empty(N, H4, dtype=torch.float32, device=dev)        # per-node [gq | gk | gv | gskip]
         escr = torch.empty(max(graph.cap, 1), 2, dtype=torch.float32, device=dev)
         delta = torch.empty(N, dtype=torch.float32, device=dev)
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
         gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
-        ws = torch.empty(_lib.load().qot_tconv_bwd_dst_workspace_floats(N, H, D), dtype=torch.float32, device=dev)
+        rpb = 1024 // H                                   # destinations per workgroup
+        tiled = maps is not None
+        if tiled:
+            # table gradient = sum over graphs: pre-reduced over `rpb` graphs inside the kernels
+            B, n = maps[3]
+            gb = (B + rpb - 1) // rpb
+            gpart = torch.empty(gb, n, H4, dtype=torch.float32, device=dev)
+            gskip = torch.empty(N, H, dtype=torch.float32, device=dev)
+            tile_args = (n, B, P(gpart))
+            gq_ptr, gs_ptr, gk_ptr, gv_ptr, ldg = None, P(gskip), None, None, H
+            ws_rows = n * gb * rpb
+        else:
+            gnode = torch.empty(N, H4, dtype=torch.float32, device=dev)    # per-node [gq | gk | gv | gskip]
+            tile_args = (0, 0, None)
+            gq_ptr, gs_ptr, gk_ptr, gv_ptr, ldg = _off(gnode, 0), _off(gnode, 3 * H), _off(gnode, H), _off(gnode, 2 * H), H4
+            ws_rows = N
+        ws = torch.empty(_lib.load().qot_tconv_bwd_dst_workspace_floats(ws_rows, H, D), dtype=torch.float32, device=dev)
         # one launch: back through the fused leaky_relu+dropout (mask regenerated), destination pass,
         # and the lin_edge weight gradient; gskip then holds the gradient wrt the conv output
         if ctx.act is not None:
@@ -278,18 +293,20 @@ class TConvFn(torch.autograd.Function):
             act_args = (None, 0.0, 0.0, 0, None)
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
                   P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap),
-                  _off(gnode, 0), _off(gnode, 3 * H), H4, P(escr), P(delta), P(pds), P(pal), *act_args,
-                  P(gwe), P(ws), N, H, D)
-        _lib.call("qot_tconv_bwd_src", _off(gnode, 3 * H), H4, _off(qkvs, 0), H4, P(escr), P(delta),
-                  P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), P(colf_t), _off(gnode, H), _off(gnode, 2 * H),
-                  H4, N, H)
-        if maps is None:
+                  gq_ptr, gs_ptr, ldg, P(escr), P(delta), P(pds), P(pal), *act_args,
+                  P(gwe), P(ws), *tile_args, N, H, D)
+        _lib.call("qot_tconv_bwd_src", gs_ptr, ldg, _off(qkvs, 0), H4, P(escr), P(delta),
+                  P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), P(colf_t), gk_ptr, gv_ptr,
+                  ldg, *tile_args, N, H)
+        if not tiled:
             gq = gnode
         else:
-            B, n = maps[3]
-            gq = torch.empty(n, H4, dtype=torch.float32, device=dev)       # table rows = sum over graphs
-            wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
-            _lib.call("qot_rowsum_wide", P(gnode), B, n * H4, P(gq), P(wsr))
+            if gb == 1:
+                gq = gpart[0]
+            else:
+                gq = torch.empty(n, H4, dtype=torch.float32, device=dev)   # table rows = sum over graph groups
+                wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
+                _lib.call("qot_rowsum_wide", P(gpart), gb, n * H4, P(gq), P(wsr))
             if n < qkvs.shape[0]:                              # table rows no node refers to
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
         return gq, None, gwe, None, None, None

@@ -130,7 +130,13 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
  * itself, so grad_skip then holds the gradient wrt the conv output -- pass IT (ld_go = ld_g) to
  * qot_tconv_bwd_src.  grad_w_edge != NULL: grad of lin_edge.weight [H,D] is produced as well
  * (fixed-order block partials; workspace qot_tconv_bwd_dst_workspace_floats(N,H,D) floats),
- * replacing qot_tconv_wedge_grad. */
+ * replacing qot_tconv_wedge_grad.
+ * Tile mode (grad_part != NULL; table mode with node_ids == arange(tile_n) for each of the tile_B graphs,
+ * N = tile_n * tile_B): a workgroup takes node r of RPB = 1024/H consecutive graphs and pre-reduces the
+ * table gradient over them: grad_part[ceil(tile_B/RPB), tile_n, 4H] receives the partial sums of
+ * grad_q (columns 0..H) and grad_skip (3H..4H) here and of grad_k / grad_v (H..3H) in qot_tconv_bwd_src;
+ * the caller sums its first axis.  grad_q may then be NULL; grad_skip[N,H] is still written per node
+ * (the source pass gathers it). */
 size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D);
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,
@@ -138,14 +144,15 @@ int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, con
                       const int32_t* rowmap, float* grad_q, float* grad_skip, int ld_g, float* escr,
                       float* delta, float* pds, float* pal, const float* y_act, float act_slope, float act_p,
                       uint64_t act_seed, const int64_t* act_step, float* grad_w_edge, float* workspace,
-                      int64_t N, int H, int D, qot_stream_t stream);
+                      int tile_n, int64_t tile_B, float* grad_part, int64_t N, int H, int D, qot_stream_t stream);
 /* bwd, source pass: grad_k, grad_v [N,H] (ld_g).  qmap_t (table mode, else NULL): table row of
  * each out-edge's destination (node_ids[col_t]) for the q gather; grad_out (row stride ld_go) and
  * delta stay per node. */
 int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, const float* escr,
                       const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
                       const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
-                      int ld_g, int64_t N, int H, qot_stream_t stream);
+                      int ld_g, int tile_n, int64_t tile_B, float* grad_part, int64_t N, int H,
+                      qot_stream_t stream);
 
 /* grad of lin_edge.weight: gWe[H,D] = (q/sqrt(H))^T pds + grad_out^T pal  (deterministic two-stage
  * column reduction; workspace: qot_tconv_wedge_workspace_floats(H, D) floats). */
