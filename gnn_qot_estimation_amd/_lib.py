@@ -79,7 +79,8 @@ SIGNATURES = {
     "qot_rowsum_wide": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "qot_head_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
     "qot_head_bwd_workspace_floats": (_sz, [_int, _int]),
-    "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
+    "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p,
+                            _p, _f, _f, _u64, _p, _p]),
     "qot_act_bwd_colsum": (_int, [_p, _p, _p, _i64, _int, _f, _f, _u64, _p, _p, _p, _p]),
     "qot_smooth_l1_workspace_floats": (_sz, []),
     "qot_smooth_l1": (_int, [_p, _p, _i64, _f, _p, _p, _p, _p]),

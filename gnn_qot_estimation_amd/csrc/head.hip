@@ -62,8 +62,15 @@ template <int H>
 __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ pooled, const float* __restrict__ hidden,
     const int32_t* __restrict__ ptr, const float* __restrict__ w0, const float* __restrict__ w3,
-    float* __restrict__ gx, float* __restrict__ partials, int64_t B, int O, ActParams act) {
+    float* __restrict__ gx, float* __restrict__ partials, int64_t B, int O, ActParams act,
+    const float* __restrict__ x_in, ActParams in_act) {
+    // x_in != NULL: the head's input is y = dropout(leaky_relu(conv)) (the conv kernel's fused epilogue,
+    // models.py:58-59) and gx is to be the gradient wrt the conv output: the pool backward multiplies by
+    // act'(y) on the fly (mask regenerated from in_act) and the block also accumulates the column sums of
+    // that gradient = the conv's bias gradient (partials slot [.. | H]).
     constexpr int PER = H * H / 256;                  // gW0 elements per thread (16 at H = 64)
+    __shared__ float4 cred[256];
+    float4 acs = f4zero();                            // threads t < H/4: bias-gradient columns 4t..4t+3
     __shared__ float gh[H];
     __shared__ float gp[H];
     __shared__ float pp[H];
@@ -118,13 +125,43 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         const float inv = 1.0f / (float)((end - beg) > 1 ? (end - beg) : 1);
         constexpr int TPR = H / 4, RPB = 256 / TPR;
         const int sub = t % TPR, slot = t / TPR;
+        float4 cs = f4zero();
         if (slot < RPB) {
             const float4 v = make_float4(gp[4 * sub] * inv, gp[4 * sub + 1] * inv, gp[4 * sub + 2] * inv, gp[4 * sub + 3] * inv);
-            for (int64_t r = beg + slot; r < end; r += RPB) st4(gx + r * H + 4 * sub, v);
+            if (!x_in) {
+                for (int64_t r = beg + slot; r < end; r += RPB) st4(gx + r * H + 4 * sub, v);
+            } else {
+                for (int64_t r = beg + slot; r < end; r += RPB) {
+                    const int64_t flat = r * H + 4 * sub;
+                    const float4 yy = ld4(x_in + flat);
+                    uint64_t z = 0;
+                    if (in_act.thr16) z = act_hash64(in_act.seed, (uint64_t)in_act.step[0], (uint64_t)flat >> 2);
+                    float vi[4] = {v.x, v.y, v.z, v.w};
+                    const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool keep = in_act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= in_act.thr16) : true;
+                        vi[c] = vi[c] * (keep ? in_act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : in_act.slope);
+                    }
+                    const float4 o4 = make_float4(vi[0], vi[1], vi[2], vi[3]);
+                    st4(gx + flat, o4);
+                    cs = add4(cs, o4);
+                }
+            }
+        }
+        if (x_in) {
+            cred[t] = cs;
+            __syncthreads();
+            if (t < TPR) {
+                float4 s4 = cred[t];
+                for (int k2 = 1; k2 < RPB; ++k2) s4 = add4(s4, cred[k2 * TPR + t]);
+                acs = add4(acs, s4);
+            }
         }
         __syncthreads();
     }
-    float* part = partials + (int64_t)blockIdx.x * (H * H + H + O * H + O);
+    float* part = partials + (int64_t)blockIdx.x * (H * H + H + O * H + O + (x_in ? H : 0));
+    if (x_in && t < H / 4) st4(part + H * H + H + O * H + O + 4 * t, acs);
 #pragma unroll
     for (int e = 0; e < PER; ++e) part[t * PER + e] = aw0[e];
     if (t < H) {
@@ -169,14 +206,15 @@ extern "C" int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0,
 }
 
 extern "C" size_t qot_head_bwd_workspace_floats(int H, int O) {
-    return (size_t)kHeadBwdBlocks * (size_t)(H * H + H + O * H + O);
+    return (size_t)kHeadBwdBlocks * (size_t)(H * H + 2 * H + O * H + O);
 }
 
-// grads: [gW0 (H*H) | gb0 (H) | gW3 (O*H) | gb3 (O)] contiguous in `grads`
+// grads: [gW0 (H*H) | gb0 (H) | gW3 (O*H) | gb3 (O) | column sums of grad_x (H, only with x_in)] contiguous
 extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
                             const float* w0, const float* w3, float* grad_x, float* grads, float* workspace,
                             int64_t B, int H, int O, float slope, float p, uint64_t seed,
-                            const int64_t* step_counter, qot_stream_t stream_) {
+                            const int64_t* step_counter, const float* x_in, float in_slope, float in_p,
+                            uint64_t in_seed, const int64_t* in_step, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (B <= 0 || O <= 0) return QOT_ERR_BADARG;
     if (O > 8) return QOT_ERR_UNSUPPORTED;
@@ -184,10 +222,11 @@ extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const fl
     const ActParams ap = make_act(1, slope, p, seed, step_counter);
     int blocks = kHeadBwdBlocks;
     if (B < blocks) blocks = (int)B;
+    const ActParams in_ap = make_act(x_in ? 1 : 0, in_slope, in_p, in_seed, in_step);
     QOT_HEAD_H(H, head_bwd_kernel<kH><<<blocks, 256, 0, stream>>>(grad_out, pooled, hidden, ptr, w0, w3, grad_x,
-                                                                  workspace, B, O, ap));
+                                                                  workspace, B, O, ap, x_in, in_ap));
     QOT_LAUNCH_CHECK();
-    const int n = H * H + H + O * H + O;
+    const int n = H * H + H + O * H + O + (x_in ? H : 0);
     head_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, blocks, n, grads);
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -412,7 +412,9 @@ class NNConvFn(torch.autograd.Function):
     """NNConv(aggr='mean') = aggregate-then-GEMM (see ``csrc/nnconv.hip``)."""
 
     @staticmethod
-    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex, act=None):
+    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex, act=None, side=None):
+        """``side`` (dict shared with the consumer, see ``HeadFn``): the consumer's backward delivers the
+        gradient wrt the PRE-activation output and this layer's bias gradient in ``side["gbias"]``."""
         require_cuda(x, edge_attr, w1, b1, w2, b2, wroot, bias)
         x, edge_attr = _f32c(x), _f32c(edge_attr)
         w1, b1, w2, b2, wroot, bias = (_f32c(t) for t in (w1, b1, w2, b2, wroot, bias))
@@ -443,6 +445,7 @@ class NNConvFn(torch.autograd.Function):
                               act[3] if act is not None else None)
         ctx.graph = graph
         ctx.act = None if act is None else (act[0], act[1], act[2])
+        ctx.side = side if act is not None else None
         return out
 
     @staticmethod
@@ -450,7 +453,9 @@ class NNConvFn(torch.autograd.Function):
         x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, y, act_step = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g)
-        if ctx.act is not None:
+        if ctx.side is not None and "gbias" in ctx.side:
+            gbias = ctx.side.pop("gbias")          # consumer already went back through the activation
+        elif ctx.act is not None:
             g, gbias = act_backward_colsum(g, y, ctx.act + (act_step,))
         else:
             gbias = colsum(g)
@@ -507,7 +512,7 @@ class NNConvFn(torch.autograd.Function):
             gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
                       P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
-        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
 
 
 # ------------------------------------------------------------------ leaky_relu + dropout (a3)
@@ -564,7 +569,11 @@ class HeadFn(torch.autograd.Function):
     backward and all four parameter gradients)."""
 
     @staticmethod
-    def forward(ctx, x, ptr32, w0, b0, w3, b3, B, act):
+    def forward(ctx, x, ptr32, w0, b0, w3, b3, B, act, in_act=None, side=None):
+        """``in_act`` / ``side``: the producer of ``x`` applied ``dropout(leaky_relu(.))`` in its epilogue
+        (``in_act = (slope, p, seed, step)``) and has agreed (same ``side`` dict handed to its Function) to
+        receive the gradient wrt its PRE-activation output: backward then folds that activation backward
+        and the producer's bias gradient (``side["gbias"]``) into the pool-backward pass."""
         require_cuda(x, w0, b0, w3, b3)
         x, w0, b0, w3, b3 = (_f32c(t) for t in (x, w0, b0, w3, b3))
         N, H = x.shape
@@ -576,26 +585,34 @@ class HeadFn(torch.autograd.Function):
         out = torch.empty(B, O, dtype=torch.float32, device=dev)
         _lib.call("qot_head_fwd", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H, O,
                   float(slope), float(p if step is not None else 0.0), int(seed), P(step))
-        ctx.save_for_backward(ptr32, w0, w3, pooled, hidden, step)
+        fold = in_act is not None and side is not None
+        ctx.save_for_backward(ptr32, w0, w3, pooled, hidden, step, x if fold else None,
+                              in_act[3] if fold else None)
         ctx.cfg = (N, H, O, B, float(slope), float(p if step is not None else 0.0), int(seed))
+        ctx.fold = (float(in_act[0]), float(in_act[1] if in_act[3] is not None else 0.0), int(in_act[2])) if fold else None
+        ctx.side = side if fold else None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ptr32, w0, w3, pooled, hidden, step = ctx.saved_tensors
+        ptr32, w0, w3, pooled, hidden, step, x_in, in_step = ctx.saved_tensors
         N, H, O, B, slope, p, seed = ctx.cfg
         g = _f32c(g)
         dev = g.device
         gx = torch.empty(N, H, dtype=torch.float32, device=dev)
-        grads = torch.empty(H * H + H + O * H + O, dtype=torch.float32, device=dev)
+        nb = H * H + H + O * H + O
+        grads = torch.empty(nb + (H if ctx.fold else 0), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_head_bwd_workspace_floats(H, O), dtype=torch.float32, device=dev)
+        fold_args = (P(x_in), ctx.fold[0], ctx.fold[1], ctx.fold[2], P(in_step)) if ctx.fold else (None, 0.0, 0.0, 0, None)
         _lib.call("qot_head_bwd", P(g), P(pooled), P(hidden), P(ptr32), P(w0), P(w3), P(gx), P(grads), P(ws), B, H, O,
-                  slope, p, seed, P(step))
+                  slope, p, seed, P(step), *fold_args)
+        if ctx.fold:
+            ctx.side["gbias"] = grads[nb:]          # the producer's bias gradient; gx is wrt its pre-activation
         gw0 = grads[:H * H].view(H, H)
         gb0 = grads[H * H:H * H + H]
         gw3 = grads[H * H + H:H * H + H + O * H].view(O, H)
-        gb3 = grads[H * H + H + O * H:]
-        return gx, None, gw0, gb0, gw3, gb3, None, None
+        gb3 = grads[H * H + H + O * H:H * H + H + O * H + O]
+        return gx, None, gw0, gb0, gw3, gb3, None, None, None, None
 
 
 # ------------------------------------------------------------------ GATConv (a7)

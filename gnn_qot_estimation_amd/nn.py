@@ -101,11 +101,11 @@ class NNConv(nn.Module):
                                       "topological_training/models.py:20-24")
         return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
 
-    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None):
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None, side=None):
         if graph is None:
             graph = build_graph_index(edge_index, x.shape[0])
         w1, b1, w2, b2 = self._edge_mlp()
-        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph, act)
+        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph, act, side)
 
 
 class GATConv(nn.Module):

@@ -74,10 +74,21 @@ class TopologicalGNN(nn.Module):
             x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step))
         else:
             x = self.conv1(x, edge_index, edge_attr, graph=graph, act=self._act(0, step))
-        for layer in range(2, self.num_layers + 1):
-            x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=self._act(layer - 1, step))
         l0, l3 = self.mlp[0], self.mlp[3]
-        if x.shape[1] in (16, 32, 64, 128) and l3.out_features <= 8 and l0.out_features == x.shape[1]:
+        width = self.node_embeddings.embedding_dim
+        fused_head = width in (16, 32, 64, 128) and l3.out_features <= 8 and l0.out_features == width
+        # the read-out's backward can go back through the last conv's fused activation itself (and hand
+        # that conv its bias gradient): one pass over [N, H] instead of three
+        side = {} if (fused_head and torch.is_grad_enabled()) else None
+        last_act = None
+        for layer in range(2, self.num_layers + 1):
+            act_l = self._act(layer - 1, step)
+            last = layer == self.num_layers
+            if last:
+                last_act = act_l
+            x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=act_l,
+                                              side=side if last else None)
+        if fused_head:
             # pool + head MLP (models.py:61-63) fused: one kernel forward, one backward
             p = self.mlp[2].p if self.training else 0.0
             if self._qot_seed is None:
@@ -85,7 +96,8 @@ class TopologicalGNN(nn.Module):
             seed = (self._qot_seed + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
             act = (self.mlp[1].negative_slope, p, seed, step if p > 0.0 else None)
             ptr, B = batch_ptr_for(data, n)
-            return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act)
+            return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
+                                   last_act if side is not None else None, side)
         b32, ptr, B = batch_index_for(data, n)
         x = QF.PoolFn.apply(x, b32, ptr, B)
         return self._head(x)

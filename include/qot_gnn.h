@@ -305,7 +305,11 @@ int qot_act_bwd_colsum(const float* grad_y, const float* y, float* grad_x, int64
 /* ---- fused read-out head: global_mean_pool -> Linear(H,H) -> LeakyReLU -> Dropout -> Linear(H,O)
  * (topological_training/models.py:33-38,61-63).  fwd saves pooled[B,H] and hidden[B,H] (post dropout).
  * bwd: grad_x[N,H] (pool backward included) and grads = [gW0 | gb0 | gW3 | gb3] contiguous
- * (deterministic partial sums; workspace qot_head_bwd_workspace_floats(H, O) floats).  O <= 8. */
+ * (deterministic partial sums; workspace qot_head_bwd_workspace_floats(H, O) floats).  O <= 8.
+ * x_in != NULL (the head's input, i.e. the last conv's output y = dropout(leaky_relu(conv)) with the
+ * in_* activation parameters of that conv's epilogue, models.py:58-59): grad_x is then the gradient
+ * wrt the CONV output (the activation backward is applied while the pool gradient is written) and
+ * grads gets H more floats: its column sums = that conv's bias gradient. */
 int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
                  const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
                  float slope, float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream);
@@ -313,6 +317,7 @@ size_t qot_head_bwd_workspace_floats(int H, int O);
 int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
                  const float* w0, const float* w3, float* grad_x, float* grads, float* workspace, int64_t B,
                  int H, int O, float slope, float p, uint64_t seed, const int64_t* step_counter,
+                 const float* x_in, float in_slope, float in_p, uint64_t in_seed, const int64_t* in_step,
                  qot_stream_t stream);
 
 /* ---- SmoothL1Loss(reduction="mean", beta) value and gradient in one launch
