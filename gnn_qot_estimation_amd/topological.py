@@ -79,7 +79,7 @@ class TopologicalGNN(nn.Module):
         fused_head = width in (16, 32, 64, 128) and l3.out_features <= 8 and l0.out_features == width
         # the read-out's backward can go back through the last conv's fused activation itself (and hand
         # that conv its bias gradient): one pass over [N, H] instead of three
-        side = {} if (fused_head and torch.is_grad_enabled()) else None
+        side = {} if (fused_head and torch.is_grad_enabled() and getattr(self, "_qot_fold_head", True)) else None
         last_act = None
         for layer in range(2, self.num_layers + 1):
             act_l = self._act(layer - 1, step)

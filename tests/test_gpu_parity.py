@@ -467,3 +467,33 @@ def test_csr_by_graph_equals_general_build(cuda_device):
               max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
               P(g.invdeg), P(st), None, None, None, None, None)
     assert int(st.item()) & 2
+
+
+@pytest.mark.gpu
+def test_dropout_step_agrees_between_execution_modes(cuda_device):
+    """With dropout ON the oracle cannot be the checker (different RNG), but the engine's own modes must
+    agree with each other: table mode + pre-reduced table gradient + read-out fold (default) against the
+    per-node path without the fold -- same masks (seed / step / element indexing), same loss, same
+    gradients up to summation order."""
+    import copy
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    torch.manual_seed(11)
+    batch = S.topological_batch(2, 24, n=40, e=150).to(cuda_device)
+    a = q.TopologicalGNN(40, 64, 3, 4, dropout_p=0.5).to(cuda_device).train()
+    b = copy.deepcopy(a)
+    b._qot_fold_head = False
+    a._qot_seed = b._qot_seed = 1234567
+    plain = batch.to(cuda_device)
+    plain.uniform_node_ids = None            # forces EmbedFn + node-level projections
+    plain.edge_ptr = None                    # and the general index build
+    ya, yb = a(batch), b(plain)
+    assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
+    assert float(ya.abs().max()) > 0
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    gmax = max(float(p.grad.abs().max()) for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        err = float((pa.grad - pb.grad).abs().max()) / max(float(pb.grad.abs().max()), 1e-3 * gmax)
+        assert err <= 1e-4, (name, err)
