@@ -8,7 +8,7 @@
 
 namespace qot {
 
-constexpr int kHeadBwdBlocks = 256;
+constexpr int kHeadBwdBlocks = 512;
 
 // dynamic LDS: p[H] | h[H]
 template <int H>
