@@ -186,7 +186,7 @@ def kernel_table(model, batch):
     ws_a = torch.empty(lib.qot_nnconv_adjoint_dw_workspace_floats(D), device=dev)
     add("nnconv_adjoint_dw", lambda: _lib.call("qot_nnconv_adjoint_dw", P(gout), H, P(x), H, P(ea), P(w1), P(b1),
                                                P(g.rowptr_t), P(g.col_t), P(g.eid_t), P(g.invdeg), P(wp), P(out),
-                                               P(gwt), 0, P(ws_a), N, H, D),
+                                               P(gwt), 2, P(ws_a), N, H, D),   # 2: main kernel only (what rocprof lists)
         conv_in + 2 * N * H * 4 + 2 * KT * H * 4, 4.0 * N * KT * H, "mfma")
     add("nnconv_gradh_fused", lambda: _lib.call("qot_nnconv_gradh_fused", P(gout), H, P(x), H, P(ea), P(w1), P(b1),
                                                 P(g.rowptr), P(g.col), P(g.eid), P(g.invdeg), P(bp), P(gw1), P(gb1),

@@ -870,6 +870,7 @@ extern "C" int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const floa
                 workspace, N);
     });
     QOT_LAUNCH_CHECK();
+    if (param_layout == 2) return QOT_OK;      // profiling: main kernel only (slabs left unsummed)
     const int64_t elems = (int64_t)(2 * D + 2) * 64 * 64;
     const int per_group = 16;
     const int groups = (grid + per_group - 1) / per_group;

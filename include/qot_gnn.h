@@ -199,6 +199,8 @@ int qot_gemm_tn(const float* A, int lda, const float* G, int ldg, int64_t N, int
  * {qot_nnconv_fused(transpose=1), qot_nnconv_agg, qot_gemm_tn}.  x = the forward input rows.
  * param_layout = 1 writes the weight gradient in the parameters' own layouts instead:
  * [d nn.2.weight [H*H, K] | d nn.2.bias [H*H] | d lin.weight [H, H]] (same total size).
+ * param_layout = 2 (profiling only) launches the main kernel alone: per-workgroup slabs stay in the
+ * workspace and gwcat_t is not written -- lets bench.py time exactly the kernel rocprofv3 lists.
  * workspace: qot_nnconv_adjoint_dw_workspace_floats(D) floats. */
 size_t qot_nnconv_adjoint_dw_workspace_floats(int D);
 int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const float* x, int ld_x,
