@@ -10,7 +10,7 @@ attributes whose name contains ``index`` offset and all others (``node_ids``!) n
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional
+from typing import Iterable
 
 import torch
 

@@ -6,7 +6,6 @@ hipBLASLt on the matrix cores) -- the north star reserves MFMA for exactly those
 """
 from __future__ import annotations
 
-import math
 import os
 from typing import Optional
 

@@ -9,7 +9,6 @@ and ``state_dict`` keys as ``lightpath_training/models.py:7-45`` (SURVEY.md App.
 """
 from __future__ import annotations
 
-import torch
 from torch import nn
 
 from . import functional as QF

@@ -20,7 +20,7 @@ CPU tests and by the oracle).
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 

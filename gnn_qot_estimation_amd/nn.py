@@ -13,7 +13,6 @@ import math
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import functional as QF
