@@ -345,6 +345,22 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["gbs"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": traffic,
                                "alg_bytes_per_launch": dom["alg_bytes"], "ms_per_launch": dom["ms"]}
+        # whole-step view against both rooflines, from SURVEY.md 8(d)'s per-graph algorithmic figures:
+        # bytes: embed 2(4n+4nH) + convs (8nH+4e+4(n+1)+4eD fwd, 12nH+8e+4(n+1)+4eD bwd) + pool 2(4nH+4n+4H);
+        # flops: 3 x fwd, fwd = TransformerConv 8nH^2+2eHD+4eH + NNConv 2nH^2(K+1)+2eH(K+1)+2nH^2
+        n_, e_, H_, D_, K_, L_ = CFG["n"], CFG["e"], CFG["H"], CFG["D"], 2 * CFG["D"], CFG["layers"]
+        conv_f = 8 * n_ * H_ + 4 * e_ + 4 * (n_ + 1) + 4 * e_ * D_
+        conv_b = 12 * n_ * H_ + 8 * e_ + 4 * (n_ + 1) + 4 * e_ * D_
+        step_bytes = (2 * (4 * n_ + 4 * n_ * H_) + L_ * (conv_f + conv_b) + 2 * (4 * n_ * H_ + 4 * n_ + 4 * H_)) * CFG["B"]
+        fwd_flops = (8 * n_ * H_ * H_ + 2 * e_ * H_ * D_ + 4 * e_ * H_
+                     + (L_ - 1) * (2 * n_ * H_ * H_ * (K_ + 1) + 2 * e_ * H_ * (K_ + 1) + 2 * n_ * H_ * H_))
+        step_flops = 3.0 * fwd_flops * CFG["B"]
+        sec = dt / args.steps
+        res["step_roofline"] = {"alg_bytes_per_step": step_bytes, "hbm_GBps": step_bytes / sec / 1e9,
+                                "hbm_frac": step_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                                "alg_flops_per_step": step_flops, "mfma_TFLOPs": step_flops / sec / 1e12,
+                                "mfma_frac": step_flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                "note": "per rank; algorithmic figures of SURVEY.md 8(d)"}
         res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)
