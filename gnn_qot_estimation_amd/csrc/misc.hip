@@ -280,9 +280,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // nesterov / weight decay -- topological_training/train.py:66): buf = mu*buf + g ; p -= lr*buf.
 // first_step: buf = g (torch initialises the momentum buffer with the first gradient).
 __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    int64_t n, float lr, float mu, int first) {
+                                    int64_t n, float lr, float mu, int first, const float* __restrict__ lr_dev) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (lr_dev) lr = lr_dev[0];          // learning rate read at run time: a captured step follows the schedule
     const float b = first ? g[t] : fmaf(mu, buf[t], g[t]);
     buf[t] = b;
     p[t] = fmaf(-lr, b, p[t]);
@@ -456,7 +457,20 @@ extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || (n > 0 && (!param || !grad || !momentum_buf))) return QOT_ERR_BADARG;
     if (n > 0) {
-        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, lr, momentum, first_step);
+        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, lr, momentum, first_step,
+                                                                  nullptr);
+        QOT_LAUNCH_CHECK();
+    }
+    return QOT_OK;
+}
+
+extern "C" int qot_sgd_momentum_dev(float* param, const float* grad, float* momentum_buf, int64_t n,
+                                    const float* lr_dev, float momentum, int first_step, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || !lr_dev || (n > 0 && (!param || !grad || !momentum_buf))) return QOT_ERR_BADARG;
+    if (n > 0) {
+        sgd_momentum_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, grad, momentum_buf, n, 0.f, momentum, first_step,
+                                                                  lr_dev);
         QOT_LAUNCH_CHECK();
     }
     return QOT_OK;

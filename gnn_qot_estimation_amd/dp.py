@@ -95,17 +95,35 @@ class FusedSGD:
     (``qot_sgd_momentum``; same arithmetic as ``torch.optim.SGD`` without dampening / nesterov /
     weight decay, the reference's optimizer at ``topological_training/train.py:66``)."""
 
-    def __init__(self, flat: "FlatModel", lr: float, momentum: float = 0.0):
-        self.flat, self.lr, self.momentum = flat, float(lr), float(momentum)
+    def __init__(self, flat: "FlatModel", lr: float, momentum: float = 0.0, device_lr: bool = False):
+        """``device_lr``: keep the learning rate in device memory (``set_lr`` fills it) so a step captured in
+        a HIP graph follows a scheduler without re-capture."""
+        self.flat, self.momentum = flat, float(momentum)
         self.buf = torch.zeros_like(flat.flat_param)
         self.steps = 0          # host side; a captured graph bakes in "not the first step"
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.flat_param.device) if device_lr else None
+        self.lr = float(lr)
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        self._lr = float(value)
+        if self.lr_dev is not None:
+            self.lr_dev.fill_(self._lr)
 
     def step(self):
         from . import _lib
         if not self.flat.flat_param.is_cuda:
             raise _lib.QotError("FusedSGD runs on the GPU only (use torch.optim.SGD on CPU)")
-        _lib.call("qot_sgd_momentum", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
-                  _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, int(self.steps == 0))
+        if self.lr_dev is not None:
+            _lib.call("qot_sgd_momentum_dev", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
+                      _lib.ptr(self.buf), self.flat.numel, _lib.ptr(self.lr_dev), self.momentum, int(self.steps == 0))
+        else:
+            _lib.call("qot_sgd_momentum", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
+                      _lib.ptr(self.buf), self.flat.numel, self.lr, self.momentum, int(self.steps == 0))
         self.steps += 1
 
 

@@ -155,8 +155,88 @@ def _local_indices(idx: range, batch_size: int, rank: int, world: int) -> List[i
     return out
 
 
+class StepReplayer:
+    """HIP-graph replay of whole steps over the cached batches of an HBM-resident shard.
+
+    The reference revisits the same unshuffled chunks for 35 epochs (``train.py:79-95``).  With the shard in
+    HBM and the batch objects cached, a step's inputs are the SAME device tensors on every visit, so the
+    whole step (forward, loss, backward, optimizer update, statistics) is captured once per batch and
+    replayed afterwards: no Python, no launches, no allocation on later visits.  First visit of a batch
+    runs eagerly (it also builds and caches the graph index), the second is captured, later ones replay.
+    All captures share one memory pool (steps never overlap), the learning rate lives in device memory
+    (``FusedSGD(device_lr=True)``), dropout draws come from the device-side counter.  Batches whose
+    forward raises (``ValueError``: no LUT node) are remembered and skipped.  Single process only: a
+    collective cannot sit inside these graphs.
+    """
+
+    def __init__(self, model, kind: str, out_dim: int, device, flat: Optional[FlatModel], opt: Optional[FusedSGD]):
+        self.model, self.kind, self.out_dim, self.device = model, kind, out_dim, device
+        self.flat, self.opt = flat, opt
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs: Dict[Tuple[int, bool], object] = {}
+        self.visits: Dict[Tuple[int, bool], int] = {}
+        self.skip: set = set()
+        self.stats = {True: RegressionStats(out_dim, device), False: RegressionStats(out_dim, device)}
+        self._loss = torch.zeros((), dtype=torch.float32, device=device)
+        self._keep: List[object] = []          # batch objects whose ids key the tables
+
+    def _step(self, data, training: bool):
+        from . import functional as QF
+        fwd = _KINDS[self.kind]
+        if training:
+            # The step differentiates with respect to fresh leaves that alias the parameters
+            # (functional_call), not the Parameters themselves: a Parameter's gradient accumulator has the
+            # stream affinity of whoever created it, and one that user code keeps alive (any earlier
+            # forward whose output is still referenced) would drag a cross-stream sync into the capture
+            # (observed as a crash in capture_end).
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            leaves = {n: p.detach().requires_grad_(True) for n, p in zip(names, self.flat.params)}
+            functional = lambda d: torch.func.functional_call(self.model, leaves, (d,))
+            out, y = fwd(functional, data, self.out_dim)
+            _, g = QF.smooth_l1_loss_and_grad(out, y, loss_out=self._loss)
+            grads = torch.autograd.grad(out, list(leaves.values()), g, allow_unused=True)
+            torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                       for gr, p in zip(grads, self.flat.params)], out=self.flat.flat_grad)
+            self.opt.step()
+        else:
+            with torch.no_grad():
+                out, y = fwd(self.model, data, self.out_dim)
+                QF.smooth_l1_loss_and_grad(out, y, loss_out=self._loss)
+        self.stats[training].update(y, out, self._loss)
+
+    def run(self, data, training: bool) -> bool:
+        """One step on ``data``; returns False when the batch is (remembered as) skipped."""
+        key = (id(data), training)
+        if key in self.skip:
+            return False
+        g = self.graphs.get(key)
+        if g is not None:
+            g.replay()
+            return True
+        seen = self.visits.get(key, 0)
+        self.model.train(training)
+        if seen == 0 or (training and self.opt.steps == 0):
+            try:
+                self._step(data, training)
+            except ValueError:
+                self.skip.add(key)
+                self._keep.append(data)
+                return False
+            self.visits[key] = 1
+            self._keep.append(data)
+            return True
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            self._step(data, training)
+        self.graphs[key] = g
+        g.replay()                      # capture records, it does not execute
+        return True
+
+
 def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out_dim: int, device,
-              criterion, flat: Optional[FlatModel] = None, opt: Optional[FusedSGD] = None) -> Dict[str, object]:
+              criterion, flat: Optional[FlatModel] = None, opt: Optional[FusedSGD] = None,
+              replayer: Optional[StepReplayer] = None) -> Dict[str, object]:
     """One pass over ``indices``; trains when ``opt`` is given, else evaluates under ``no_grad``."""
     fwd = _KINDS[kind]
     rank, world = _rank_world()
@@ -170,6 +250,16 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     skipped = 0
     training = opt is not None
     model.train(training)
+    if replayer is not None and resident and world == 1:
+        st = replayer.stats[training]
+        st.buf.zero_()
+        for data in loader:
+            if not replayer.run(data, training):
+                skipped += data.num_graphs
+        res = st.result()
+        res["avg_loss"] = res["loss_sum"] / max(len(indices), 1)
+        res["skipped"] = skipped
+        return res
     with torch.set_grad_enabled(training):
         for data in loader:
             if training:
@@ -209,17 +299,23 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
 def fit(model, dataset, *, kind: str = "topological", batch_size: int = 512, num_epochs: int = 35,
         patience: int = 10, lr: float = 0.1, momentum: float = 0.9, step_size: int = 10, gamma: float = 0.5,
         chunk_fraction: float = 0.10, output_dim: int = 3, device="cuda", best_path: Optional[str] = None,
-        log: Callable[[str], None] = print) -> History:
-    """The training script's main loop (train.py:24-182) on a dataset object indexable by graph."""
+        log: Callable[[str], None] = print, replay: Optional[bool] = None) -> History:
+    """The training script's main loop (train.py:24-182) on a dataset object indexable by graph.
+
+    ``replay`` (default: on for an HBM-resident shard in a single process): steps over cached batches are
+    captured as HIP graphs on their second visit and replayed afterwards (``StepReplayer``)."""
     device = torch.device(device)
     model.to(device)
     tr, va, _ = split_ranges(len(dataset))
     flat = FlatModel(model)
     flat.broadcast_params()
-    opt = FusedSGD(flat, lr=lr, momentum=momentum)
+    rank, world = _rank_world()
+    resident = isinstance(dataset, PackedGraphs) and dataset.device is not None
+    use_replay = (resident and world == 1) if replay is None else (bool(replay) and resident and world == 1)
+    opt = FusedSGD(flat, lr=lr, momentum=momentum, device_lr=use_replay)
+    replayer = StepReplayer(model, kind, output_dim, device, flat, opt) if use_replay else None
     criterion = torch.nn.SmoothL1Loss()
     hist = History()
-    rank, _ = _rank_world()
     counter = 0
     for epoch in range(num_epochs):
         chunk = epoch_chunk(epoch, len(tr), chunk_fraction)
@@ -228,9 +324,9 @@ def fit(model, dataset, *, kind: str = "topological", batch_size: int = 512, num
         opt.lr = step_lr(lr, epoch, step_size, gamma)
         t = run_epoch(model, dataset, range(tr[0] + chunk[0], tr[0] + chunk[-1] + 1) if len(chunk) else range(0),
                       kind=kind, batch_size=batch_size, out_dim=output_dim, device=device, criterion=criterion,
-                      flat=flat, opt=opt)
+                      flat=flat, opt=opt, replayer=replayer)
         v = run_epoch(model, dataset, va, kind=kind, batch_size=batch_size, out_dim=output_dim, device=device,
-                      criterion=criterion)
+                      criterion=criterion, replayer=replayer)
         hist.loss.append(t["avg_loss"]); hist.r2.append(t["r2"])
         hist.val_loss.append(v["avg_loss"]); hist.val_r2.append(v["r2"])
         hist.skipped_graphs += t["skipped"]

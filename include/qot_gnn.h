@@ -291,6 +291,10 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
  * Both take qot_colsum_workspace_floats(C) floats of workspace. */
 int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                      float momentum, int first_step, qot_stream_t stream);
+/* same update with the learning rate read from device memory at run time, so that a step captured in a
+ * HIP graph follows the scheduler (StepLR, topological_training/train.py:67,181) without re-capture */
+int qot_sgd_momentum_dev(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,
+                         float momentum, int first_step, qot_stream_t stream);
 int qot_small_gemm(const float* A, int64_t stride_am, int64_t stride_ak, const float* B, int64_t stride_bk,
                    int64_t stride_bn, const float* bias, float* C, int ldc, int M, int N, int K,
                    int split_k, qot_stream_t stream);

@@ -103,3 +103,43 @@ def test_hbm_resident_shard_batches_and_cache():
     # the training loop accepts the resident shard (fit -> run_epoch -> cached batches)
     hist = Hn.fit(model, shard, kind="topological", batch_size=8, num_epochs=3, chunk_fraction=0.5, log=lambda s: None)
     assert hist.epochs_run == 3 and np.isfinite(hist.loss).all()
+
+
+def test_replayed_training_equals_eager_training():
+    """HBM-resident shard: steps captured per cached batch and replayed must train exactly like the eager
+    loop (same StepLR schedule through the device-side learning rate, same statistics), for both models;
+    the lightpath run includes a batch without LUT nodes that stays skipped."""
+    import copy
+    torch.manual_seed(0)
+    topo = q.PackedGraphs.from_data_list(_topological_dataset(240)).to_device("cuda")
+    base = q.TopologicalGNN(num_nodes=12, hidden_channels=16, out_channels=3, edge_dim=4, dropout_p=0.0)
+    runs = {}
+    for replay in (False, True):
+        m = copy.deepcopy(base)
+        runs[replay] = Hn.fit(m, topo, kind="topological", batch_size=16, num_epochs=7, chunk_fraction=0.5, lr=0.05,
+                              step_size=2, gamma=0.5, log=lambda s: None, replay=replay), m
+    (h0, m0), (h1, m1) = runs[False], runs[True]
+    np.testing.assert_allclose(h1.loss, h0.loss, rtol=2e-4)
+    np.testing.assert_allclose(h1.val_loss, h0.val_loss, rtol=2e-4)
+    np.testing.assert_allclose(h1.val_r2, h0.val_r2, rtol=1e-3, atol=1e-4)
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-3)
+
+    lp = S.lightpath_batch(96)
+    graphs = []
+    for g in range(96):
+        s = q.shard_graphs(lp, g, 96)
+        x = s.x.clone()
+        if 8 <= g < 12:
+            x[:, 1] = 0.0
+        graphs.append(q.Data(x=x, edge_index=s.edge_index, y=s.y, num_nodes=s.num_nodes))
+    shard = q.PackedGraphs.from_data_list(graphs).to_device("cuda")
+    lbase = q.LightpathGNN(in_channels=5, hidden_channels=8, output_dim=3, is_lut_index=1, dropout_p=0.0)
+    lruns = {}
+    for replay in (False, True):
+        m = copy.deepcopy(lbase)
+        lruns[replay] = Hn.fit(m, shard, kind="lightpath", batch_size=4, num_epochs=5, chunk_fraction=0.5,
+                               log=lambda s: None, replay=replay)
+    assert lruns[True].skipped_graphs == lruns[False].skipped_graphs > 0
+    np.testing.assert_allclose(lruns[True].loss, lruns[False].loss, rtol=2e-4)
+    np.testing.assert_allclose(lruns[True].val_loss, lruns[False].val_loss, rtol=2e-4)
