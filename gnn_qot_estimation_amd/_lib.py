@@ -25,6 +25,8 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
+ABI_VERSION = 2          # include/qot_gnn.h: QOT_ABI_VERSION
+
 SIGNATURES = {
     "qot_abi_version": (_int, []),
     "qot_error_string": (C.c_char_p, [_int]),
@@ -127,8 +129,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.qot_abi_version() != 1:
-        raise QotError("libqot_gnn ABI version mismatch")
+    if lib.qot_abi_version() != ABI_VERSION:
+        raise QotError(f"libqot_gnn ABI version {lib.qot_abi_version()} != {ABI_VERSION} expected by this package: "
+                       "rebuild with `make -C gnn_qot_estimation_amd/csrc`")
     _lib = lib
     return lib
 
