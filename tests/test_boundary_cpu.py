@@ -67,7 +67,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().qot_abi_version() == 1
+    assert _lib.load().qot_abi_version() == _lib.ABI_VERSION
     assert b"unsupported" in _lib.load().qot_error_string(-1)
 
 
