@@ -119,6 +119,17 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> Graph
         return c[key][1]
     slices = None
     ptr, eptr, sizes = getattr(data, "ptr", None), getattr(data, "edge_ptr", None), getattr(data, "graph_sizes", None)
+    if eptr is None and not gat_self_loops and ptr is not None:
+        # a PyG Batch keeps the same per-graph edge slices in `_slice_dict["edge_index"]` (host tensor)
+        sd = getattr(data, "_slice_dict", None)
+        es = sd.get("edge_index") if isinstance(sd, dict) else None
+        if isinstance(es, torch.Tensor) and es.dim() == 1 and es.numel() == ptr.numel() and es.numel() >= 2:
+            es = es.to(torch.long).cpu()
+            pc = ptr.detach().to("cpu", torch.long) if c is None or "ptr_host" not in c else c["ptr_host"]
+            eptr = es.to(ei.device)
+            sizes = (int((pc[1:] - pc[:-1]).max()), int((es[1:] - es[:-1]).max()))
+            if c is not None:
+                c["ptr_host"] = pc
     if (not gat_self_loops and ptr is not None and eptr is not None and sizes is not None
             and ptr.numel() == eptr.numel() and ptr.is_cuda and eptr.is_cuda):
         slices = (ptr, eptr, sizes[0], sizes[1])

@@ -520,3 +520,23 @@ def test_table_mode_without_edge_slices_matches_sliced_batch(cuda_device):
     ya.sum().backward(); yb.sum().backward()
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(pa.grad, pb.grad)
+
+
+@pytest.mark.gpu
+def test_pyg_style_slice_dict_enables_per_graph_index(cuda_device):
+    """A PyG ``Batch`` has no ``edge_ptr`` but keeps ``_slice_dict['edge_index']``: the one-launch index build
+    must pick that up (duck-typed here: PyG itself is not installed) and match the general build."""
+    from gnn_qot_estimation_amd import synthetic as S
+    from gnn_qot_estimation_amd.graph import build_graph_index, graph_index_for
+    b = S.topological_batch(2, 9, n=25, e=70).to(cuda_device)
+
+    class PygLike:
+        pass
+    p = PygLike()
+    p.edge_index, p.ptr, p.num_graphs = b.edge_index, b.ptr, b.num_graphs
+    p._slice_dict = {"edge_index": b.edge_ptr.cpu(), "x": None}
+    g = graph_index_for(p, b.num_nodes)
+    ref = build_graph_index(b.edge_index, b.num_nodes)
+    assert g.ptr32 is not None                         # by-graph path was taken
+    for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg"):
+        assert torch.equal(getattr(g, name), getattr(ref, name)), name
