@@ -540,3 +540,35 @@ def test_pyg_style_slice_dict_enables_per_graph_index(cuda_device):
     assert g.ptr32 is not None                         # by-graph path was taken
     for name in ("rowptr", "col", "eid", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg"):
         assert torch.equal(getattr(g, name), getattr(ref, name)), name
+
+
+@pytest.mark.gpu
+def test_table_mode_detected_for_batches_without_hint(cuda_device):
+    """A batch object without ``uniform_node_ids`` (a PyG Batch has none) is inspected once on the device;
+    table mode then runs and gives the hinted batch's results, and a non-uniform batch stays on the node path."""
+    import copy
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    torch.manual_seed(3)
+    b = S.topological_batch(2, 10, n=20, e=60).to(cuda_device)
+
+    class PygLike:
+        pass
+    p = PygLike()
+    for name in ("edge_index", "edge_attr", "node_ids", "batch", "ptr", "num_graphs"):
+        setattr(p, name, getattr(b, name))
+    p.x = None
+    a = q.TopologicalGNN(20, 32, 3, 4, dropout_p=0.0).to(cuda_device).train()
+    c = copy.deepcopy(a)
+    ya, yc = a(b), c(p)
+    assert p.uniform_node_ids == 20 and "tmaps" in p._qot_cache
+    assert float((ya - yc).abs().max()) <= 1e-6 * float(ya.abs().max())
+    # permuted ids in one graph: not uniform -> node path, still correct (compare against itself hinted None)
+    p2 = PygLike()
+    for name in ("edge_index", "edge_attr", "batch", "ptr", "num_graphs"):
+        setattr(p2, name, getattr(b, name))
+    ids = b.node_ids.clone(); ids[:20] = ids[:20].flip(0)
+    p2.node_ids, p2.x = ids, None
+    y2 = c(p2)
+    assert p2.uniform_node_ids is None and "tmaps" not in p2._qot_cache
+    assert y2.shape == ya.shape
