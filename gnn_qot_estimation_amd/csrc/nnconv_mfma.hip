@@ -321,6 +321,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
     constexpr int CH = (GQ % 5 == 0) ? 5 : 4;
     __shared__ __attribute__((aligned(16))) float Ut[KT * 32];
     __shared__ __attribute__((aligned(16))) float red[8 * 3 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float xs[32 * 64];      // the tile's own x rows (B operand of X^T U)
     float4* Ut4 = reinterpret_cast<float4*>(Ut);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r31 = lane & 31, hi = lane >> 5;
@@ -333,14 +334,19 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dw[t][r] = 0.f;
-    // transposed-read addressing of the U tile for this lane's dW rows (kcol = 32*mb + r31)
-    int dwbase[TPW], dwmask[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int kcol = (mb0 + 4 * t) * 32 + r31;
+    // Transposed-read addressing of the U tile for this lane's dW rows (kcol = 32*(mb0 + 4t) + r31).
+    // Float index of U[row jj][kcol] = base(t) + ((jj ^ m) << 2) with base(t) = base(0) + 4096 t and the
+    // XOR mask m = (4 mb0 + (r31 >> 3)) & 7 the same for every t.  With jj = 8a + 2b + hi the XOR only
+    // touches b and hi: (jj ^ m) << 2 = 32 a + ((((b ^ (m >> 1)) << 1) | (hi ^ (m & 1))) << 2), so four
+    // per-lane offsets (b = 0..3) plus compile-time immediates (a, t) address all 80 reads of a tile.
+    int dwoff[4];
+    {
+        const int kcol = mb0 * 32 + r31;
         const int gg = kcol >> 3, within = kcol & 7;
-        dwbase[t] = ((2 * gg + (within & 1)) * 32) * 4 + (within >> 1);
-        dwmask[t] = gg & 7;
+        const int base0 = ((2 * gg + (within & 1)) * 32) * 4 + (within >> 1);
+        const int m = gg & 7;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dwoff[b] = base0 + ((((b ^ (m >> 1)) << 1) | (hi ^ (m & 1))) << 2);
     }
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nh * (KT / 8) + kq * GQ) * 64 + lane;
 
@@ -415,15 +421,14 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                 *s1 = make_float2(acc[kk].y, acc[kk].w);
             }
         }
-        // x rows of the tile's own nodes (B operand of the weight-gradient product) and the first
-        // WcatT fragments: requested right after the gather's LDS writes, ahead of the barrier
-        // (hoisting them above the gather spilled: the gather needs the registers)
-        float xb[16];
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            const int64_t j = tile0 + 2 * sidx + hi;
-            const float v = xf[(j < N ? j : N - 1) * ldx + ah * 32 + r31];
-            xb[sidx] = (j < N) ? v : 0.f;
+        // x rows of the tile's own nodes (B operand of the weight-gradient product) go to LDS next to the U
+        // tile (16 lanes per row, one float4 each): holding them in 16 VGPRs through both MFMA loops was
+        // part of what pushed this kernel into scratch.
+        {
+            const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
+            const int64_t j = tile0 + il;
+            const float4 v = (j < N) ? ld4(xf + j * ldx + 4 * sub) : f4zero();
+            *reinterpret_cast<float4*>(&xs[il * 64 + 4 * sub]) = v;
         }
         float4 bc[CH], bn[CH];
 #pragma unroll
@@ -446,16 +451,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                 for (int u = 0; u < CH; ++u) bc[u] = bn[u];
             }
         }
-        // ---- weight gradient: gWcat^T[(k,o)][a] += sum_j U[j][(k,o)] x[j][a]
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            const int jj = 2 * sidx + hi;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const float a = Ut[dwbase[t] + ((jj ^ dwmask[t]) << 2)];
-                dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[sidx], dw[t], 0, 0, 0);
-            }
-        }
+        // (published BEFORE the weight-gradient loop so that the 16 accumulator registers are dead there)
         // ---- K quarters of grad_x meet through LDS: quarter q finishes accumulator registers
         // 4q..4q+3 of its column half (hands the other 12 over), so all 8 waves share the stores.
         // red[((owner*2 + nh)*3 + slot)*4 + rr][lane], slot = which of the 3 other quarters wrote it
@@ -467,6 +463,31 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         else if (kq == 2) { QOT_GIVE(0, 1) QOT_GIVE(1, 1) QOT_GIVE(3, 2) }
         else { QOT_GIVE(0, 2) QOT_GIVE(1, 2) QOT_GIVE(2, 2) }
 #undef QOT_GIVE
+        // ---- weight gradient: gWcat^T[(k,o)][a] += sum_j U[j][(k,o)] x[j][a]
+        // Step s = 4a + b multiplies tile rows 2s, 2s+1.  Software-pipelined by hand: the TPW transposed
+        // reads of step s+1 are issued before the TPW MFMAs of step s (left to itself the compiler
+        // reused ONE temporary and put `ds_read_b32; s_waitcnt lgkmcnt(0)` in front of every MFMA --
+        // half of all MFMAs of this kernel waited for their own LDS read).
+        {
+            float abuf[2][TPW], xbuf[2];
+            const float* xsl = xs + hi * 64 + ah * 32 + r31;          // row 2s + hi -> + 128 s
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) abuf[0][t] = Ut[dwoff[0] + t * 4096];
+            xbuf[0] = xsl[0];
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                const int cur = sidx & 1;
+                if (sidx + 1 < 16) {
+                    const int sn = sidx + 1;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) abuf[cur ^ 1][t] = Ut[dwoff[sn & 3] + (sn >> 2) * 32 + t * 4096];
+                    xbuf[cur ^ 1] = xsl[sn * 128];
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[cur][t], xbuf[cur], dw[t], 0, 0, 0);
+            }
+        }
         lds_barrier();
         {
             float v[4];
