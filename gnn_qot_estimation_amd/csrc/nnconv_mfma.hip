@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
     constexpr int MB = KT / 32;             // 32-row blocks of gWcat^T (20)
     constexpr int TPW = MB * 2 / 8;         // dW tiles per wave (5)
     static_assert(GQ % 4 == 0 || GQ % 5 == 0, "chunking");
-    constexpr int CH = (GQ % 5 == 0) ? 5 : 4;
+    constexpr int CH = (GQ % 4 == 0) ? 4 : 5;
     __shared__ __attribute__((aligned(16))) float Ut[KT * 32];
     __shared__ __attribute__((aligned(16))) float red[8 * 3 * 4 * 64];
     __shared__ __attribute__((aligned(16))) float xs[32 * 64];      // the tile's own x rows (B operand of X^T U)
