@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     constexpr int K = 2 * D;
     constexpr int KM = (K + 1) * 64;        // inner dimension held in LDS (blocks 0..K)
     constexpr int GM = KM / 16;             // float4 B groups per wave for the main part
-    constexpr int CH = (GM % 6 == 0) ? 6 : 4;   // prefetch chunk (GM = 8D+4: divisible by 4, by 6 for D=4)
+    constexpr int CH = 4;                       // prefetch chunk (GM = 8D+4 is divisible by 4); 6 spilled inside the MFMA loop
     __shared__ __attribute__((aligned(16))) float At[KM * 32];
     const int64_t ntiles = (N + 31) / 32;
     // persistent: 2 workgroups per CU walk the tiles; the two CU-mates drift out of phase so
@@ -224,9 +224,13 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     // root groups (2*GM + kh*4)..
     const float4* wpn = reinterpret_cast<const float4*>(Wp) + (int64_t)nh * (2 * GM + 8) * 64 + lane;
     const float4* wp = wpn + (int64_t)kh * GM * 64;
+    // one base pointer + immediate offsets (as separate expressions the four addresses were materialised
+    // outside the tile loop, spilled, and reloaded from scratch -- with a full wait each -- every tile)
+    const float4* rbp = wpn + (int64_t)(2 * GM + kh * 4) * 64;
+    asm volatile("" : "+v"(rbp));          // opaque: one live base per tile, the four offsets stay immediates
     float4 rb[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rb[u] = wpn[(2 * GM + kh * 4 + u) * 64];
+    for (int u = 0; u < 4; ++u) rb[u] = rbp[u * 64];
     // B fragments (L2) of chunk ch+1 are requested before the 4*CH MFMAs of chunk ch issue
     float4 bc[CH], bn[CH];
 #pragma unroll
