@@ -434,6 +434,10 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
             const float4 v = (j < N) ? ld4(xf + j * ldx + 4 * sub) : f4zero();
             *reinterpret_cast<float4*>(&xs[il * 64 + 4 * sub]) = v;
         }
+        // WcatT fragments: two buffers used alternately, two chunks per trip of a rolled loop.  Written as
+        // `bc = bn` copies the compiler put `s_waitcnt vmcnt(0)` at the top of every chunk, i.e. waited for
+        // the prefetch it had just issued (fully unrolled it spilled instead).
+        constexpr int NCH = GQ / CH;
         float4 bc[CH], bn[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) bc[u] = wp[u * 64];
@@ -443,16 +447,23 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
         {
+            int ch = 0;
 #pragma unroll 1
-            for (int ch = 0; ch < GQ / CH; ++ch) {
-                if (ch + 1 < GQ / CH) {
+            for (; ch + 1 < NCH; ch += 2) {
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) bn[u] = wp[((ch + 1) * CH + u) * 64];
-                }
+                for (int u = 0; u < CH; ++u) bn[u] = wp[((ch + 1) * CH + u) * 64];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) c = mfma_group(Ut4, kq * GQ + ch * CH + u, hi, r31, bc[u], c);
+                if (ch + 2 < NCH) {
 #pragma unroll
-                for (int u = 0; u < CH; ++u) bc[u] = bn[u];
+                    for (int u = 0; u < CH; ++u) bc[u] = wp[((ch + 2) * CH + u) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) c = mfma_group(Ut4, kq * GQ + (ch + 1) * CH + u, hi, r31, bn[u], c);
+            }
+            if (NCH & 1) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) c = mfma_group(Ut4, kq * GQ + (NCH - 1) * CH + u, hi, r31, bc[u], c);
             }
         }
         // (published BEFORE the weight-gradient loop so that the 16 accumulator registers are dead there)
