@@ -43,10 +43,28 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) {
 // Sum over an aligned group of G consecutive lanes (G power of two <= 64).  Only lanes of
 // the same group exchange data, so a wave may hold groups with different trip counts as
 // long as each group is uniformly active.
+// lane permutation inside a row of 16 lanes on the DPP path of the VALU (no LDS crossbar, no s_waitcnt)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over an aligned group of G consecutive lanes, result in every lane of the group.  Groups of up to 16
+// lanes stay inside a DPP row: quad_perm [1,0,3,2] and [2,3,0,1] pair lanes inside a quad, row_half_mirror
+// pairs the quads of an 8-lane half, row_mirror the two halves -- each step adds two partial sums of
+// disjoint lane sets, and a + b == b + a makes the paired lanes agree bit for bit.  (Written with
+// __shfl_xor every step was a ds_bpermute_b32 + s_waitcnt lgkmcnt: four LDS round trips per edge in the
+// TransformerConv kernels.)  Wider groups keep the shuffle butterfly for the steps that cross rows.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G > 16) {
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        for (int o = G / 2; o >= 16; o >>= 1) v += __shfl_xor(v, o);
+    }
+    if constexpr (G >= 16) v += dpp_move<0x140>(v);      // row_mirror: lane i <-> 15 - i
+    if constexpr (G >= 8) v += dpp_move<0x141>(v);       // row_half_mirror: i <-> 7 - i
+    if constexpr (G >= 4) v += dpp_move<0x4E>(v);        // quad_perm [2,3,0,1]
+    if constexpr (G >= 2) v += dpp_move<0xB1>(v);        // quad_perm [1,0,3,2]
     return v;
 }
 
