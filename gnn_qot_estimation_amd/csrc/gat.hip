@@ -101,9 +101,7 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
         for (int v = 0; v < G::NV; ++v) {
             const int c = 4 * (sub + G::TPR * v);
             float4 zj = ld4(z + j * G::HC + c);
-            float da = dot4(gi[v], zj);
-#pragma unroll
-            for (int o = G::LPH / 2; o > 0; o >>= 1) da += __shfl_xor(da, o);
+            float da = group_sum<G::LPH>(dot4(gi[v], zj));
             float raw = a_src[j * HEADS + hh[v]] + ad[v];
             float s = raw > 0.f ? raw : ns * raw;
             float lk = raw > 0.f ? 1.0f : ns;

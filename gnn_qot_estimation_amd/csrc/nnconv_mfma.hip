@@ -729,18 +729,18 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
                             for (int m = 0; m < 4; ++m) {
                                 const float keep = (sub & 4) ? pd[m + 4] : pd[m];
                                 const float send = (sub & 4) ? pd[m] : pd[m + 4];
-                                t4[m] = keep + __shfl_xor(send, 4);
+                                t4[m] = keep + dpp_move<0x141>(send);      // partner 7 - sub (bit 2 differs): DPP, no LDS crossbar
                             }
                             float t2[2];
 #pragma unroll
                             for (int m = 0; m < 2; ++m) {
                                 const float keep = (sub & 2) ? t4[m + 2] : t4[m];
                                 const float send = (sub & 2) ? t4[m] : t4[m + 2];
-                                t2[m] = keep + __shfl_xor(send, 2);
+                                t2[m] = keep + dpp_move<0x4E>(send);       // partner sub ^ 2
                             }
                             const float keep = (sub & 1) ? t2[1] : t2[0];
                             const float send = (sub & 1) ? t2[0] : t2[1];
-                            const float tot = keep + __shfl_xor(send, 1);     // k = 8*q + sub
+                            const float tot = keep + dpp_move<0xB1>(send);   // partner sub ^ 1; k = 8*q + sub
                             float pre = brow[q];
 #pragma unroll
                             for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);

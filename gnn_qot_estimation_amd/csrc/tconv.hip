@@ -232,12 +232,8 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
                     float ee[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
-                    float s = dot4(qi, kr[u]), da = dot4(gi, vr[u]);
-#pragma unroll
-                    for (int o = TPR / 2; o > 0; o >>= 1) {
-                        s += __shfl_xor(s, o);
-                        da += __shfl_xor(da, o);
-                    }
+                    const float s_part = dot4(qi, kr[u]), da_part = dot4(gi, vr[u]);
+                    float s = group_sum<TPR>(s_part), da = group_sum<TPR>(da_part);
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         s = fmaf(qe[d], ee[d], s);
