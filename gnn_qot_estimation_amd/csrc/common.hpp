@@ -49,6 +49,20 @@ __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// Value of lane SRC (compile-time, 0..7) of every aligned 8-lane group, in all lanes of the group:
+// quad_perm broadcast inside the quads, row_half_mirror carries it to the other quad, a select keeps the
+// right one -- three VALU operations instead of a ds_bpermute_b32 round trip.  `upper` = (lane & 4) != 0.
+template <int SRC>
+__device__ __forceinline__ float group8_bcast(float v, bool upper) {
+    const float t = dpp_move<(SRC & 3) * 0x55>(v);
+    const float w = dpp_move<0x141>(t);
+    return (upper == ((SRC & 4) != 0)) ? t : w;
+}
+template <int SRC>
+__device__ __forceinline__ int group8_bcast(int v, bool upper) {
+    return __builtin_bit_cast(int, group8_bcast<SRC>(__builtin_bit_cast(float, v), upper));
+}
+
 // Sum over an aligned group of G consecutive lanes, result in every lane of the group.  Groups of up to 16
 // lanes stay inside a DPP row: quad_perm [1,0,3,2] and [2,3,0,1] pair lanes inside a quad, row_half_mirror
 // pairs the quads of an 8-lane half, row_mirror the two halves -- each step adds two partial sums of

@@ -82,34 +82,43 @@ __device__ __forceinline__ void nnconv_gather_tile(
             }
         }
         const int cnt = (end - base < 8) ? end - base : 8;
-        for (int u0 = 0; u0 < cnt; u0 += 4) {
-            float4 xa[4], xb[4];
-            float sc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int src = u0 + u;                       // lane of the group that owns this edge
-                const int64_t j = __shfl(myj, src, 8);
-                sc[u] = __shfl(mysc, src, 8);
-                const bool live = src < cnt;
-                const float* xr = x + (live ? j : 0) * ldx + c0;
-                xa[u] = ld4(xr);
-                xb[u] = ld4(xr + 4);
-                if (!live) sc[u] = 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int src = u0 + u;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) {
-                    float h = __shfl(myh[kk], src, 8);
-                    if (src >= cnt) h = 0.f;
-                    acc0[kk] = fma4(h, xa[u], acc0[kk]);
-                    acc1[kk] = fma4(h, xb[u], acc1[kk]);
-                }
-                acc0[K] = fma4(sc[u], xa[u], acc0[K]);
-                acc1[K] = fma4(sc[u], xb[u], acc1[K]);
-            }
+        const bool upper = (sub & 4) != 0;
+        // lanes 0..7 of the group hold edges base..base+7; broadcasts with compile-time source lanes run on
+        // the DPP path (as __shfl with a runtime lane each was a ds_bpermute_b32 round trip: ten per edge)
+#define QOT_EDGE4(U0)                                                                                   \
+        {                                                                                               \
+            float4 xa[4], xb[4];                                                                        \
+            float sc[4];                                                                                \
+            int jj[4];                                                                                  \
+            jj[0] = group8_bcast<U0 + 0>(myj, upper); jj[1] = group8_bcast<U0 + 1>(myj, upper);         \
+            jj[2] = group8_bcast<U0 + 2>(myj, upper); jj[3] = group8_bcast<U0 + 3>(myj, upper);         \
+            sc[0] = group8_bcast<U0 + 0>(mysc, upper); sc[1] = group8_bcast<U0 + 1>(mysc, upper);       \
+            sc[2] = group8_bcast<U0 + 2>(mysc, upper); sc[3] = group8_bcast<U0 + 3>(mysc, upper);       \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+                const bool live = U0 + u < cnt;                                                         \
+                const float* xr = x + (live ? (int64_t)jj[u] : 0) * ldx + c0;                           \
+                xa[u] = ld4(xr);                                                                        \
+                xb[u] = ld4(xr + 4);                                                                    \
+                if (!live) sc[u] = 0.f;                                                                 \
+            }                                                                                           \
+            _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                          \
+                float h[4];                                                                             \
+                h[0] = group8_bcast<U0 + 0>(myh[kk], upper); h[1] = group8_bcast<U0 + 1>(myh[kk], upper); \
+                h[2] = group8_bcast<U0 + 2>(myh[kk], upper); h[3] = group8_bcast<U0 + 3>(myh[kk], upper); \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+                    const float hv = (U0 + u < cnt) ? h[u] : 0.f;                                       \
+                    acc0[kk] = fma4(hv, xa[u], acc0[kk]);                                               \
+                    acc1[kk] = fma4(hv, xb[u], acc1[kk]);                                               \
+                }                                                                                       \
+            }                                                                                           \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+                acc0[K] = fma4(sc[u], xa[u], acc0[K]);                                                  \
+                acc1[K] = fma4(sc[u], xb[u], acc1[K]);                                                  \
+            }                                                                                           \
         }
+        QOT_EDGE4(0)
+        if (cnt > 4) QOT_EDGE4(4)
+#undef QOT_EDGE4
     }
     if (i < N) {
         if (!TRANSPOSE) {
