@@ -292,12 +292,46 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = c[r] + red[((2 + nh) * 8 + r) * 64 + lane] + bz;
         }
+        // Dropout draws: one 64-bit hash serves the four columns of a float4 group, i.e. the four lanes of
+        // a quad for the same row.  Each lane hashes two of its eight rows and the quad shares them through
+        // quad_perm broadcasts (2 hashes + 12 DPP moves per lane instead of 8 hashes: the 64-bit
+        // multiplies of the hash were ~5 % of this kernel's VALU time).
+        uint32_t zlo[8], zhi[8];
+        const bool drop = act.enabled && act.thr16;
+        if (drop) {
+            const int jq = r31 & 3;
+            uint32_t mylo[2], myhi[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rr = kh * 8 + 2 * jq + t;
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+                const uint64_t flat = (uint64_t)((tile0 + row) * 64 + colg);
+                const uint64_t z = act_hash64(act.seed, (uint64_t)act.step[0], flat >> 2);
+                mylo[t] = (uint32_t)z; myhi[t] = (uint32_t)(z >> 32);
+            }
+#define QOT_ZSHARE(S)                                                                                   \
+            zlo[2 * (S)] = __builtin_amdgcn_update_dpp(0, mylo[0], (S) * 0x55, 0xF, 0xF, true);         \
+            zhi[2 * (S)] = __builtin_amdgcn_update_dpp(0, myhi[0], (S) * 0x55, 0xF, 0xF, true);         \
+            zlo[2 * (S) + 1] = __builtin_amdgcn_update_dpp(0, mylo[1], (S) * 0x55, 0xF, 0xF, true);     \
+            zhi[2 * (S) + 1] = __builtin_amdgcn_update_dpp(0, myhi[1], (S) * 0x55, 0xF, 0xF, true);
+            QOT_ZSHARE(0) QOT_ZSHARE(1) QOT_ZSHARE(2) QOT_ZSHARE(3)
+#undef QOT_ZSHARE
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int rr = kh * 8 + r;
             const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
             const int64_t i = tile0 + row;
-            if (i < N) out[i * 64 + colg] = act_apply1(v[r], act, (uint64_t)(i * 64 + colg));
+            float y = v[r];
+            if (act.enabled) {
+                y = y > 0.f ? y : act.slope * y;
+                if (drop) {
+                    const uint64_t z = ((uint64_t)zhi[r] << 32) | zlo[r];
+                    const bool keep = ((uint32_t)(z >> (16 * (colg & 3))) & 0xFFFFu) >= act.thr16;
+                    y = keep ? y * act.keep_scale : 0.f;
+                }
+            }
+            if (i < N) out[i * 64 + colg] = y;
         }
     }
     QOT_STAMP(5)
