@@ -186,19 +186,15 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
         key_out[rpt[ji >> 16] + rank_out[e]] = e;
     }
     __syncthreads();
+    // rows: order the keys (LDS only) and write the per-row outputs; rank_in / rank_out are free by now and
+    // take the row of every slot, so that the per-slot outputs can be written slot-parallel (coalesced)
+    int* row_of = rank_in;
+    int* row_of_t = rank_out;
     for (int r = threadIdx.x; r < 2 * n; r += 256) {
         if (r < n) {
             const int beg = rp[r], end = rp[r + 1];
             sort_row_keys(key_in, beg, end);
-            for (int p = beg; p < end; ++p) {
-                const int key = key_in[p];
-                const int64_t src = n0 + (int64_t)(ends[key] >> 16);
-                col[e0 + p] = (int32_t)src;
-                if (node_ids) colf[e0 + p] = (int32_t)node_ids[src];
-                eid[e0 + p] = (int32_t)(e0 + key);
-                row[e0 + p] = (int32_t)(n0 + r);
-                slot_of[key] = p;
-            }
+            for (int p = beg; p < end; ++p) { row_of[p] = r; slot_of[key_in[p]] = p; }
             const int d = end - beg;
             invdeg[n0 + r] = 1.0f / (float)(d > 1 ? d : 1);
             rowptr[n0 + r] = (int32_t)(e0 + beg);
@@ -206,18 +202,25 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
             const int jj = r - n;
             const int beg = rpt[jj], end = rpt[jj + 1];
             sort_row_keys(key_out, beg, end);
-            for (int t = beg; t < end; ++t) {
-                const int key = key_out[t];
-                const int64_t dst = n0 + (int64_t)(ends[key] & 0xFFFFu);
-                col_t[e0 + t] = (int32_t)dst;
-                if (node_ids) colf_t[e0 + t] = (int32_t)node_ids[dst];
-                eid_t[e0 + t] = (int32_t)(e0 + key);
-            }
+            for (int t = beg; t < end; ++t) row_of_t[t] = jj;
             rowptr_t[n0 + jj] = (int32_t)(e0 + beg);
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < m; t += 256) pos_t[e0 + t] = (int32_t)(e0 + slot_of[key_out[t]]);
+    for (int p = threadIdx.x; p < m; p += 256) {
+        const int key = key_in[p];
+        const int64_t src = n0 + (int64_t)(ends[key] >> 16);
+        col[e0 + p] = (int32_t)src;
+        if (node_ids) colf[e0 + p] = (int32_t)node_ids[src];
+        eid[e0 + p] = (int32_t)(e0 + key);
+        row[e0 + p] = (int32_t)(n0 + row_of[p]);
+        const int kt = key_out[p];
+        const int64_t dst = n0 + (int64_t)(ends[kt] & 0xFFFFu);
+        col_t[e0 + p] = (int32_t)dst;
+        if (node_ids) colf_t[e0 + p] = (int32_t)node_ids[dst];
+        eid_t[e0 + p] = (int32_t)(e0 + kt);
+        pos_t[e0 + p] = (int32_t)(e0 + slot_of[kt]);
+    }
     if (b == B - 1 && threadIdx.x == 0) { rowptr[N] = (int32_t)E; rowptr_t[N] = (int32_t)E; }
 }
 
