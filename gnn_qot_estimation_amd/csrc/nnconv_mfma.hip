@@ -241,19 +241,42 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) rb[u] = rbp[u * 64];
     // B fragments (L2) of chunk ch+1 are requested before the 4*CH MFMAs of chunk ch issue
-    float4 bc[CH], bn[CH];
+    // B fragments are requested TWO chunks (32 MFMAs, ~2000 cycles) ahead, three buffers rotating with
+    // compile-time roles: an L2 round trip is then covered by this wave's own MFMAs, so a workgroup keeps
+    // the pipe fed while its CU-mate is gathering (with one chunk of lookahead the MFMA phase only ran at
+    // full rate when both workgroups were in it).
+    constexpr int NCH = GM / CH;
+    float4 b0[CH], b1[CH], b2[CH];
 #pragma unroll
-    for (int u = 0; u < CH; ++u) bc[u] = wp[u * 64];
+    for (int u = 0; u < CH; ++u) { b0[u] = wp[u * 64]; b1[u] = wp[(CH + u) * 64]; }
+    int ch = 0;
 #pragma unroll 1
-    for (int ch = 0; ch < GM / CH; ++ch) {
-        if (ch + 1 < GM / CH) {
+    for (; ch + 2 < NCH; ch += 3) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) bn[u] = wp[((ch + 1) * CH + u) * 64];
+        for (int u = 0; u < CH; ++u) b2[u] = wp[((ch + 2) * CH + u) * 64];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, b0[u], c);
+        if (ch + 3 < NCH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) b0[u] = wp[((ch + 3) * CH + u) * 64];
         }
 #pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, bc[u], c);
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 1) * CH + u, hi, r31, b1[u], c);
+        if (ch + 4 < NCH) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) bc[u] = bn[u];
+            for (int u = 0; u < CH; ++u) b1[u] = wp[((ch + 4) * CH + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 2) * CH + u, hi, r31, b2[u], c);
+    }
+    // tail when the chunk count is not a multiple of three (b0 = chunk ch, b1 = chunk ch + 1 are loaded)
+    if (ch < NCH) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, b0[u], c);
+    }
+    if (ch + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 1) * CH + u, hi, r31, b1[u], c);
     }
     QOT_STAMP(2)
     lds_barrier();                         // everyone is done with blocks 0..K
