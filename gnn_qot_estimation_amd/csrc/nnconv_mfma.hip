@@ -246,37 +246,32 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     // the pipe fed while its CU-mate is gathering (with one chunk of lookahead the MFMA phase only ran at
     // full rate when both workgroups were in it).
     constexpr int NCH = GM / CH;
-    float4 b0[CH], b1[CH], b2[CH];
+    constexpr int NB = 4;                      // buffers: fragments are requested NB - 1 chunks ahead
+    float4 bb[NB][CH];
 #pragma unroll
-    for (int u = 0; u < CH; ++u) { b0[u] = wp[u * 64]; b1[u] = wp[(CH + u) * 64]; }
+    for (int q = 0; q < NB - 1; ++q)
+#pragma unroll
+        for (int u = 0; u < CH; ++u) bb[q][u] = wp[(q * CH + u) * 64];
     int ch = 0;
 #pragma unroll 1
-    for (; ch + 2 < NCH; ch += 3) {
+    for (; ch + NB <= NCH; ch += NB) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) b2[u] = wp[((ch + 2) * CH + u) * 64];
+        for (int q = 0; q < NB; ++q) {
+            if (ch + q + NB - 1 < NCH) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, b0[u], c);
-        if (ch + 3 < NCH) {
+                for (int u = 0; u < CH; ++u) bb[(q + NB - 1) % NB][u] = wp[((ch + q + NB - 1) * CH + u) * 64];
+            }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) b0[u] = wp[((ch + 3) * CH + u) * 64];
+            for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + q) * CH + u, hi, r31, bb[q][u], c);
         }
+    }
+    // tail: chunks ch .. NCH-1 are already in buffers 0 .. (their loads were issued above)
 #pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 1) * CH + u, hi, r31, b1[u], c);
-        if (ch + 4 < NCH) {
+    for (int q = 0; q < NB - 1; ++q) {
+        if (ch + q < NCH) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) b1[u] = wp[((ch + 4) * CH + u) * 64];
+            for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + q) * CH + u, hi, r31, bb[q][u], c);
         }
-#pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 2) * CH + u, hi, r31, b2[u], c);
-    }
-    // tail when the chunk count is not a multiple of three (b0 = chunk ch, b1 = chunk ch + 1 are loaded)
-    if (ch < NCH) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + ch * CH + u, hi, r31, b0[u], c);
-    }
-    if (ch + 1 < NCH) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + 1) * CH + u, hi, r31, b1[u], c);
     }
     QOT_STAMP(2)
     lds_barrier();                         // everyone is done with blocks 0..K
