@@ -858,6 +858,13 @@ static int num_cus() {
     return n;
 }
 
+extern "C" int qot_nnconv_fused_ws(const float* x, int ld_x, const float* edge_attr, const float* w1,
+                                   const float* b1, const int32_t* rowptr, const int32_t* col,
+                                   const int32_t* edge_ids, const float* invdeg, int transpose,
+                                   const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                                   int act, float act_slope, float act_p, uint64_t act_seed,
+                                   const int64_t* act_step, qot_stream_t stream);
+
 static int g_variant = 0;   // ablation switch for tools/ablate_nnconv.py (0 = production)
 extern "C" void qot_debug_set_variant(int v) { g_variant = v; }
 extern "C" void qot_debug_stamps(unsigned long long* host8, int reset) {
@@ -879,6 +886,11 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
     if (H != 64) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
     if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
+    static int use_ws = -1;
+    if (use_ws < 0) { const char* e = getenv("QOT_NNCONV_WS"); use_ws = (e && e[0] == '1') ? 1 : 0; }
+    if (use_ws && D <= 4 && !g_variant)
+        return qot_nnconv_fused_ws(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, transpose, w_perm, bias,
+                                   out, N, H, D, act, act_slope, act_p, act_seed, act_step, stream);
     int grid = grid_for(N, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     const ActParams ap = make_act(act, act_slope, act_p, act_seed, act_step);
