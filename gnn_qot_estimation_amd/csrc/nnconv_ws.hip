@@ -58,6 +58,230 @@ __device__ unsigned long long g_ws_stamps[8];
         t_prev = _t;                                                                 \
     }
 
+struct WsTile {           // wave-uniform description of one 32-row tile
+    int64_t tile0;
+    int e0, ne, valid;
+};
+
+__device__ __forceinline__ WsTile ws_tile_info(int64_t it, int64_t ntiles, int64_t N, const int32_t* __restrict__ rowptr) {
+    WsTile T;
+    const int64_t tile = ws_xcd_tile(it, ntiles);
+    T.valid = tile >= 0;
+    T.tile0 = T.valid ? tile * 32 : 0;
+    {
+        // vector loads on purpose: scalar loads share lgkmcnt with LDS, so the next LDS wait would also wait
+        // for them (a full L2 round trip in the middle of the MFMA phase); ws_tile_uniform() is called an
+        // iteration later, when the values have long arrived.  Unconditional (an invalid tile reads row 0):
+        // loads under a branch made hipcc wait for them at the end of the branch.
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const int64_t tend = !T.valid ? 0 : (T.tile0 + 32 < N ? T.tile0 + 32 : N);
+        T.e0 = rowptr[T.tile0 + z];
+        T.ne = rowptr[tend + z];
+    }
+    return T;
+}
+
+__device__ __forceinline__ WsTile ws_tile_uniform(WsTile T) {
+    const int e0 = __builtin_amdgcn_readfirstlane(T.e0), e1 = __builtin_amdgcn_readfirstlane(T.ne);
+    T.e0 = e0;
+    T.ne = e1 - e0;
+    return T;
+}
+
+// Per-slot metadata of one staging round, carried in registers between the pipeline stages.
+template <int D>
+struct WsMeta {
+    int src, eid, rp;
+    float ee[D];
+    float sc;
+};
+
+template <int D, bool TRANSPOSE>
+__device__ __forceinline__ void ws_meta_l1(WsMeta<D>& m, const WsTile& T, int lo, int64_t N,
+                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                           const int32_t* __restrict__ eidx) {
+    // all loads unconditional with clamped indices (idle threads read element 0; the host side guarantees one
+    // readable element): values are selected where they are consumed, nothing waits here
+    const int t = threadIdx.x;
+    const int cnt = T.ne - lo < kWsEC ? T.ne - lo : kWsEC;
+    const int p = t < cnt ? T.e0 + lo + t : 0;
+    m.src = col[p];
+    m.eid = eidx[p];
+    const int64_t ii = (T.valid && t < 33) ? (T.tile0 + t < N ? T.tile0 + t : N) : 0;
+    m.rp = rowptr[ii];
+}
+
+template <int D, bool TRANSPOSE>
+__device__ __forceinline__ void ws_meta_l2(WsMeta<D>& m, const WsTile& T, int lo, const float* __restrict__ ea,
+                                           const float* __restrict__ invdeg) {
+    // unconditional (idle threads hold edge 0 / row 0): a lane-masked or branched load here made hipcc put
+    // `s_waitcnt vmcnt(0)` into every later MFMA block
+    m.sc = 1.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) m.ee[d] = ea[(int64_t)m.eid * D + d];
+    if (TRANSPOSE) m.sc = invdeg[m.src];
+}
+
+// edge-MLP hidden vector h = relu(W1 ea + b1) (x the adjoint's mean scale) -> LDS, with the slot's source row.
+// own != 0: also describe the 32 destinations' own rows (root slab) in slots kWsEC..kWsEC+31
+template <int D>
+__device__ __forceinline__ void ws_meta_write(const WsMeta<D>& m, const WsTile& T, int lo, int own, int64_t N,
+                                              const float (&w1r)[2 * D * D], const float (&b1r)[2 * D],
+                                              float* __restrict__ hb, int* __restrict__ rp, int* __restrict__ srcbuf) {
+    constexpr int K = 2 * D;
+    const int t = threadIdx.x;
+    const int cnt = T.ne - lo < kWsEC ? T.ne - lo : kWsEC;
+    if (t < cnt) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            float hv = b1r[kk];
+#pragma unroll
+            for (int d = 0; d < D; ++d) hv = fmaf(w1r[kk * D + d], m.ee[d], hv);
+            hb[t * kWsHW + kk] = fmaxf(hv, 0.f) * m.sc;
+        }
+        hb[t * kWsHW + K] = m.sc;
+        hb[t * kWsHW + K + 1] = 0.f;
+        srcbuf[t] = m.src;
+    } else if (own && t >= kWsEC && t < kWsSlots) {
+        const int64_t ii = T.tile0 + (t - kWsEC);
+        const bool ok = T.valid && ii < N;
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk) hb[t * kWsHW + kk] = 0.f;
+        hb[t * kWsHW + K + 1] = ok ? 1.0f : 0.f;
+        srcbuf[t] = ok ? (int)ii : 0;
+    }
+    if (own && t < 33) rp[t] = T.valid ? m.rp - T.e0 : 0;
+}
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 * lane.
+// Issued from an asm statement on purpose: hipcc does not know the destination of the builtin form and
+// puts a full `s_waitcnt vmcnt(0)` in front of every later LDS read (measured: the whole DMA latency sat
+// inside the MFMA phase).  An asm load is absent from its bookkeeping; the pipeline waits for the rows
+// itself (vmcnt(0) before the barrier that publishes them).
+__device__ __forceinline__ void ws_glds16(const float* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// source rows -> LDS by DMA: 16 lanes per row, 4 rows (1 KiB) per wave-instruction
+__device__ __forceinline__ void ws_dma_rows(float* __restrict__ xb, const int* __restrict__ srcbuf, int cnt, int own,
+                                            const float* __restrict__ x, int ldx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t xb_lds = (uint32_t)(size_t)(lds_ptr_t)xb;
+    int src[kWsSlots / 32];
+#pragma unroll
+    for (int q = 0; q < kWsSlots / 32; ++q) src[q] = srcbuf[32 * q + 4 * wave + (lane >> 4)];
+#pragma unroll
+    for (int q = 0; q < kWsSlots / 32; ++q) {
+        const int sbase = 32 * q + 4 * wave;
+        const int slot = sbase + (lane >> 4);
+        const bool live = slot < cnt || (own && slot >= kWsEC);
+        if (live) {
+            const int chunk = (lane & 15) ^ (slot & 15);
+            ws_glds16(x + (int64_t)src[q] * ldx + chunk * 4,
+                      __builtin_amdgcn_readfirstlane(xb_lds + (uint32_t)sbase * 256u));
+        }
+    }
+}
+
+struct WsLane {           // a lane's (= destination row's) slice of the staged round
+    int beg, deg, n_it, maxit, ownslot;
+    float inv;
+};
+
+__device__ __forceinline__ WsLane ws_lane_params(const int* __restrict__ rp, int lo, int own, float inv) {
+    const int r = threadIdx.x & 31;
+    WsLane L;
+    int beg = rp[r] - lo, end = rp[r + 1] - lo;
+    beg = beg < 0 ? 0 : beg;
+    end = end > kWsEC ? kWsEC : end;
+    L.beg = beg;
+    L.deg = end > beg ? end - beg : 0;
+    L.n_it = L.deg + (own ? 1 : 0);
+    int maxit = L.n_it;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const int o = __shfl_xor(maxit, off);
+        maxit = o > maxit ? o : maxit;
+    }
+    L.maxit = __builtin_amdgcn_readfirstlane(maxit);
+    L.ownslot = kWsEC + r;
+    L.inv = inv;
+    return L;
+}
+
+// One block: 8 k-steps per lane half (one slab, 8 consecutive channels), 16 MFMAs.
+__device__ __forceinline__ void ws_block(const float4* __restrict__ xb4, const float* __restrict__ hb, const WsLane& L,
+                                         int kk0, const float (&w)[8][2], f32x16& c0, f32x16& c1) {
+    const int slab = kk0 >> 6, cq = (kk0 & 63) >> 2;
+    float4 a0 = f4zero(), a1 = f4zero();
+#pragma unroll 1
+    for (int d0 = 0; d0 < L.maxit; d0 += 4) {      // 4 edges in flight: 4 weight reads + 8 row reads, then 32 FMAs
+        float wv[4];
+        float4 xa[4], xc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u;
+            const bool isedge = d < L.deg;
+            const int slot = isedge ? L.beg + d : L.ownslot;
+            const float wr = hb[slot * kWsHW + slab];
+            wv[u] = d < L.n_it ? (isedge ? wr * L.inv : wr) : 0.f;
+            const int pos = cq ^ (slot & 15);
+            xa[u] = xb4[slot * 16 + pos];
+            xc[u] = xb4[slot * 16 + (pos ^ 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 = fma4(wv[u], xa[u], a0);
+            a1 = fma4(wv[u], xc[u], a1);
+        }
+    }
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], w[i][0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], w[i][1], c1, 0, 0, 0);
+    }
+}
+
+// K-eighths of a finished tile: [wave][row][64] partials in LDS -> bias / activation -> 256-B row stores
+// (`step` = the dropout counter, read once per kernel: as a load inside the loop it was waited for on the spot)
+__device__ __forceinline__ void ws_epilogue(const float4* __restrict__ red4, int64_t tile0, float4 bias4,
+                                            const ActParams& act, uint64_t step, float* __restrict__ out, int64_t N) {
+    const int t = threadIdx.x;
+    const int row = t >> 4, c4 = t & 15;
+    float4 v = bias4;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float4 p = red4[(w * 32 + row) * 16 + c4];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int64_t i = tile0 + row;
+    if (i < N) {
+        if (act.enabled) {          // as act_apply4 (common.hpp), with the counter in a register
+            float q[4] = {v.x, v.y, v.z, v.w};
+            uint64_t z = 0;
+            if (act.thr16) z = act_hash64(act.seed, step, (uint64_t)(i * 16 + c4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float y = q[c] > 0.f ? q[c] : act.slope * q[c];
+                if (act.thr16) y = (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= act.thr16) ? y * act.keep_scale : 0.f;
+                q[c] = y;
+            }
+            v = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        *reinterpret_cast<float4*>(out + i * 64 + 4 * c4) = v;
+    }
+}
+
+// Software pipeline over the workgroup's tiles A (multiplying), B (rows in flight), C (metadata in flight):
+//   top      rows(A) + meta(A) + meta(B) in LDS, partial sums of the previous tile in the other row buffer
+//   1  issue C's index loads            2  block 0 of A            3  previous tile's epilogue (LDS sums, stores)
+//   4  issue C's edge-feature loads     5  barrier; DMA rows(B) into the buffer the epilogue just drained
+//   6  blocks 1.. of A (+ extra rounds when A has more in-edges than slots)
+//   7  barrier; C's metadata -> LDS, A's partial sums -> A's row buffer; wait for rows(B); barrier
 template <int D, bool TRANSPOSE, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
@@ -66,15 +290,29 @@ __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
     const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act) {
     constexpr int K = 2 * D, S = K + 2, KT = S * 64;
     constexpr int NBLK = KT / 128;          // blocks of 8 k-steps per lane half
-    constexpr int GT = KT / 8;              // Wp groups of 4 k-steps... (8 k values) per column half
+    constexpr int GT = KT / 8;              // Wp groups (8 k values each) per column half
     static_assert(S <= kWsHW, "weight row too narrow");
-    __shared__ __attribute__((aligned(16))) float xbuf[kWsSlots * 64];
-    __shared__ __attribute__((aligned(16))) float hbuf[kWsSlots * kWsHW];
+    static_assert(kWsSlots * 64 >= 8 * 32 * 64, "row buffer doubles as the K-eighth exchange");
+    __shared__ __attribute__((aligned(16))) float xbuf[2][kWsSlots * 64];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][kWsSlots * kWsHW];
     __shared__ int srcbuf[kWsSlots];
-    __shared__ int rpbuf[36];
+    __shared__ int rpbuf[2][36];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     const int base_kk = wave * (KT / 8) + h * (KT / 16);
+    const int64_t ntiles = (N + 31) / 32;
+
+    WsTile A = ws_tile_uniform(ws_tile_info(0, ntiles, N, rowptr));
+    if (!A.valid) return;
+    WsTile B = ws_tile_uniform(ws_tile_info(1, ntiles, N, rowptr));
+    WsTile C = ws_tile_uniform(ws_tile_info(2, ntiles, N, rowptr));
+    // edge-MLP first layer: loaded once (inside the loop these uniform loads would be scalar loads, and a
+    // scalar load in flight turns every LDS wait into a wait for it)
+    float w1r[K * D], b1r[K];
+#pragma unroll
+    for (int q = 0; q < K * D; ++q) w1r[q] = w1[q];
+#pragma unroll
+    for (int q = 0; q < K; ++q) b1r[q] = b1[q];
 
     // resident weights: wreg[b][i][nh] = Wcat[base_kk + 8b + i][32 nh + r]   (Wp: see qot_nnconv_fused)
     float wreg[NBLK][8][2];
@@ -87,157 +325,88 @@ __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
                 const int g = (base_kk >> 3) + b;
                 wreg[b][i][nh] = Wp[(((int64_t)nh * GT + g) * 64 + (i & 1) * 32 + r) * 4 + (i >> 1)];
             }
+    const float4 bias4 = bias ? ld4(bias + 4 * (t & 15)) : f4zero();
+    const uint64_t drop_step = (act.enabled && act.thr16) ? (uint64_t)act.step[0] : 0;
 
-    const int64_t ntiles = (N + 31) / 32;
-    const float4* xb4 = reinterpret_cast<const float4*>(xbuf);
+    // ---- prologue: A staged synchronously, B's metadata behind it
+    WsMeta<D> m;
+    ws_meta_l1<D, TRANSPOSE>(m, A, 0, N, rowptr, col, eidx);
+    ws_meta_l2<D, TRANSPOSE>(m, A, 0, ea, invdeg);
+    ws_meta_write<D>(m, A, 0, 1, N, w1r, b1r, hbuf[0], rpbuf[0], srcbuf);
+    ws_lds_barrier();
+    ws_dma_rows(xbuf[0], srcbuf, A.ne < kWsEC ? A.ne : kWsEC, 1, x, ldx);
+    ws_meta_l1<D, TRANSPOSE>(m, B, 0, N, rowptr, col, eidx);
+    ws_meta_l2<D, TRANSPOSE>(m, B, 0, ea, invdeg);
+    ws_lds_barrier();                              // srcbuf(A) consumed by every wave's DMA issue
+    ws_meta_write<D>(m, B, 0, 1, N, w1r, b1r, hbuf[1], rpbuf[1], srcbuf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws_lds_barrier();
+
+    float inv = TRANSPOSE ? 1.0f : invdeg[A.tile0 + r < N ? A.tile0 + r : 0];
+    int p = 0;
+    bool have_prev = false;
+    int64_t prev_tile0 = 0;
+    unsigned long long t_prev = 0;
+    if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int64_t it = 0;; ++it) {
-        const int64_t tile = ws_xcd_tile(it, ntiles);
-        if (tile < 0) break;
-        const int64_t tile0 = tile * 32;
-        const int64_t tend = tile0 + 32 < N ? tile0 + 32 : N;
-        const int e0 = rowptr[tile0];
-        const int ne = rowptr[tend] - e0;
+        const WsTile Dn = ws_tile_info(it + 3, ntiles, N, rowptr);
+        const float4* xb4 = reinterpret_cast<const float4*>(xbuf[p]);
+        const float* hb = hbuf[p];
         f32x16 c0, c1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { c0[j] = 0.f; c1[j] = 0.f; }
-        const int64_t irow = tile0 + r;
-        unsigned long long t_prev = 0;
-        if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
-        const float inv = (!TRANSPOSE && irow < N) ? invdeg[irow] : 1.0f;
-
+        const float inv_next = TRANSPOSE ? 1.0f : invdeg[(B.valid && B.tile0 + r < N) ? B.tile0 + r : 0];
+        ws_meta_l1<D, TRANSPOSE>(m, C, 0, N, rowptr, col, eidx);                      // 1
+        WsLane L = ws_lane_params(rpbuf[p], 0, 1, inv);
+        ws_block(xb4, hb, L, base_kk, wreg[0], c0, c1);                              // 2
+        QOT_WS_STAMP(0)
+        if (have_prev)                                                               // 3
+            ws_epilogue(reinterpret_cast<const float4*>(xbuf[p ^ 1]), prev_tile0, bias4, act, drop_step, out, N);
+        QOT_WS_STAMP(1)
+        ws_meta_l2<D, TRANSPOSE>(m, C, 0, ea, invdeg);                                // 4
+        ws_lds_barrier();                                                            // 5
+        if (B.valid) ws_dma_rows(xbuf[p ^ 1], srcbuf, B.ne < kWsEC ? B.ne : kWsEC, 1, x, ldx);
+        QOT_WS_STAMP(2)
+#pragma unroll
+        for (int b = 1; b < NBLK; ++b) ws_block(xb4, hb, L, base_kk + 8 * b, wreg[b], c0, c1);   // 6
+        QOT_WS_STAMP(3)
 #pragma unroll 1
-        for (int lo = 0; lo == 0 || lo < ne; lo += kWsEC) {
-            const int cnt = ne - lo < kWsEC ? ne - lo : kWsEC;
-            // ---- per-slot metadata: source row, edge-MLP hidden vector (x mean scale of the adjoint)
-            if (t < 33) {
-                const int64_t ii = tile0 + t < N ? tile0 + t : N;
-                rpbuf[t] = rowptr[ii] - e0;
-            }
-            if (t < cnt) {
-                const int p = e0 + lo + t;
-                const int src = col[p];
-                const int64_t e = eidx[p];
-                float ee[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-                const float sc = TRANSPOSE ? invdeg[src] : 1.0f;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) {
-                    float hv = b1[kk];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) hv = fmaf(w1[kk * D + d], ee[d], hv);
-                    hbuf[t * kWsHW + kk] = fmaxf(hv, 0.f) * sc;
-                }
-                hbuf[t * kWsHW + K] = sc;
-                hbuf[t * kWsHW + K + 1] = 0.f;
-                srcbuf[t] = src;
-            } else if (lo == 0 && t >= kWsEC && t < kWsSlots) {
-                const int64_t ii = tile0 + (t - kWsEC);
-#pragma unroll
-                for (int kk = 0; kk <= K; ++kk) hbuf[t * kWsHW + kk] = 0.f;
-                hbuf[t * kWsHW + K + 1] = ii < N ? 1.0f : 0.f;
-                srcbuf[t] = (int)(ii < N ? ii : N - 1);
-            }
-            QOT_WS_STAMP(0)
+        for (int lo = kWsEC; lo < A.ne; lo += kWsEC) {       // rare: more in-edges than slots
+            WsMeta<D> mx;
             ws_lds_barrier();
-            QOT_WS_STAMP(1)
-            // ---- source rows -> LDS by DMA: 16 lanes per row, 4 rows per wave-instruction
-#pragma unroll
-            for (int q = 0; q < kWsSlots / 32; ++q) {
-                const int sbase = 32 * q + 4 * wave;
-                const int slot = sbase + (lane >> 4);
-                const bool live = slot < cnt || (lo == 0 && slot >= kWsEC);
-                if (live) {
-                    const int src = srcbuf[slot];
-                    const int chunk = (lane & 15) ^ (slot & 15);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(x + (int64_t)src * ldx + chunk * 4),
-                                                     (lds_ptr_t)(xbuf + sbase * 64), 16, 0, 0);
-                }
-            }
+            ws_meta_l1<D, TRANSPOSE>(mx, A, lo, N, rowptr, col, eidx);
+            ws_meta_l2<D, TRANSPOSE>(mx, A, lo, ea, invdeg);
+            ws_meta_write<D>(mx, A, lo, 0, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf);
+            ws_lds_barrier();
+            ws_dma_rows(xbuf[p], srcbuf, A.ne - lo < kWsEC ? A.ne - lo : kWsEC, 0, x, ldx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            QOT_WS_STAMP(2)
             ws_lds_barrier();
-            QOT_WS_STAMP(3)
-
-            // ---- operand formation + MFMA
-            int beg = rpbuf[r] - lo, end = rpbuf[r + 1] - lo;
-            beg = beg < 0 ? 0 : beg;
-            end = end > kWsEC ? kWsEC : end;
-            const int deg = end > beg ? end - beg : 0;
-            const int n_it = deg + (lo == 0 ? 1 : 0);
-            int maxit = n_it;
+            const WsLane Lx = ws_lane_params(rpbuf[p], lo, 0, inv);
 #pragma unroll
-            for (int off = 32; off; off >>= 1) {
-                const int o = __shfl_xor(maxit, off);
-                maxit = o > maxit ? o : maxit;
-            }
-            maxit = __builtin_amdgcn_readfirstlane(maxit);
-            const int ownslot = kWsEC + r;
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                const int kk0 = base_kk + 8 * b;
-                const int slab = kk0 >> 6, cq = (kk0 & 63) >> 2;
-                float4 a0 = f4zero(), a1 = f4zero();
-#pragma unroll 1
-                for (int d0 = 0; d0 < maxit; d0 += 4) {      // 4 edges in flight: 4 weight reads + 8 row reads, then 32 FMAs
-                    float wv[4];
-                    float4 xa[4], xc[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int d = d0 + u;
-                        const bool isedge = d < deg;
-                        const int slot = isedge ? beg + d : ownslot;
-                        const float wr = hbuf[slot * kWsHW + slab];
-                        wv[u] = d < n_it ? (isedge ? wr * inv : wr) : 0.f;
-                        const int pos = cq ^ (slot & 15);
-                        xa[u] = xb4[slot * 16 + pos];
-                        xc[u] = xb4[slot * 16 + (pos ^ 1)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        a0 = fma4(wv[u], xa[u], a0);
-                        a1 = fma4(wv[u], xc[u], a1);
-                    }
-                }
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wreg[b][i][0], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wreg[b][i][1], c1, 0, 0, 0);
-                }
-            }
-            QOT_WS_STAMP(4)
-            ws_lds_barrier();                      // every wave is done with this round's rows
-            QOT_WS_STAMP(5)
+            for (int b = 0; b < NBLK; ++b) ws_block(xb4, hb, Lx, base_kk + 8 * b, wreg[b], c0, c1);
         }
-
-        // ---- K-eighths meet through LDS (aliases the row buffer), bias / activation, 256-B row stores
-        float* red = xbuf;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-            red[(wave * 32 + row) * 64 + r] = c0[j];
-            red[(wave * 32 + row) * 64 + 32 + r] = c1[j];
-        }
-        ws_lds_barrier();
+        ws_lds_barrier();                                                            // 7
+        QOT_WS_STAMP(4)
+        ws_meta_write<D>(m, C, 0, 1, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf);
         {
-            const int row = t >> 4, c4 = t & 15;
-            float4 v = bias ? ld4(bias + 4 * c4) : f4zero();
+            float* red = xbuf[p];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float4 p = xb4[(w * 32 + row) * 16 + c4];
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            const int64_t i = tile0 + row;
-            if (i < N) {
-                v = act_apply4(v, act, (uint64_t)(i * 16 + c4));
-                *reinterpret_cast<float4*>(out + i * 64 + 4 * c4) = v;
+            for (int j = 0; j < 16; ++j) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                red[(wave * 32 + row) * 64 + r] = c0[j];
+                red[(wave * 32 + row) * 64 + 32 + r] = c1[j];
             }
         }
-        ws_lds_barrier();                          // `red` consumed before the next tile's DMA lands
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QOT_WS_STAMP(5)
+        ws_lds_barrier();
         QOT_WS_STAMP(6)
+        prev_tile0 = A.tile0; have_prev = true;
+        A = B; B = C; C = ws_tile_uniform(Dn); p ^= 1; inv = inv_next;
+        if (!A.valid) break;
     }
+    ws_epilogue(reinterpret_cast<const float4*>(xbuf[p ^ 1]), prev_tile0, bias4, act, drop_step, out, N);
 }
 
 }  // namespace qot
@@ -262,6 +431,11 @@ extern "C" int qot_nnconv_fused_ws(const float* x, int ld_x, const float* edge_a
     if (H != 64 || D < 1 || D > 4) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
     if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
+    // the kernel's index / feature loads are unconditional with clamped indices: an edge-less batch still
+    // needs one readable element behind each pointer
+    if (!col) col = rowptr;
+    if (!edge_ids) edge_ids = rowptr;
+    if (!edge_attr) edge_attr = x;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
