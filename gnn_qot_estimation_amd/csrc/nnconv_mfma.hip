@@ -58,7 +58,15 @@ __device__ __forceinline__ void nnconv_gather_tile(
     for (int kk = 0; kk <= K; ++kk) { acc0[kk] = f4zero(); acc1[kk] = f4zero(); }
     root0 = f4zero(); root1 = f4zero();
     int beg = 0, end = 0;
-    if (i < N) { beg = rowptr[i]; end = rowptr[i + 1]; }
+    // the row's own loads (mean scale, root row) are issued BEFORE the edge loop: behind it they were one more
+    // exposed memory round trip per tile
+    float srow = 0.f;
+    if (i < N) {
+        beg = rowptr[i]; end = rowptr[i + 1];
+        if (!TRANSPOSE) srow = invdeg[i];
+        root0 = ld4(x + i * ldx + c0);
+        root1 = ld4(x + i * ldx + c0 + 4);
+    }
     for (int base = beg; base < end; base += 8) {
         // one edge per lane: indices, edge features, edge-MLP hidden vector
         const int p = base + sub;
@@ -120,14 +128,9 @@ __device__ __forceinline__ void nnconv_gather_tile(
         if (cnt > 4) QOT_EDGE4(4)
 #undef QOT_EDGE4
     }
-    if (i < N) {
-        if (!TRANSPOSE) {
-            const float s = invdeg[i];
+    if (!TRANSPOSE) {
 #pragma unroll
-            for (int kk = 0; kk <= K; ++kk) { acc0[kk] = scale4(s, acc0[kk]); acc1[kk] = scale4(s, acc1[kk]); }
-        }
-        root0 = ld4(x + i * ldx + c0);
-        root1 = ld4(x + i * ldx + c0 + 4);
+        for (int kk = 0; kk <= K; ++kk) { acc0[kk] = scale4(srow, acc0[kk]); acc1[kk] = scale4(srow, acc1[kk]); }
     }
     float4* At4 = reinterpret_cast<float4*>(At);
 #pragma unroll
@@ -196,6 +199,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     constexpr int CH = 4;                       // prefetch chunk (GM = 8D+4 is divisible by 4); 6 spilled inside the MFMA loop
     __shared__ __attribute__((aligned(16))) float At[KM * 32];
     const int64_t ntiles = (N + 31) / 32;
+    // read once per kernel: inside the tile loop each was a load consumed on the spot (an L2 round trip per tile)
+    const float bz = bias ? bias[((threadIdx.x >> 6) & 1) * 32 + (threadIdx.x & 31)] : 0.f;
+    const uint64_t drop_step = (act.enabled && act.thr16) ? (uint64_t)act.step[0] : 0;
     // persistent: 2 workgroups per CU walk the tiles; the two CU-mates drift out of phase so
     // one gathers while the other owns the MFMA pipes
 #pragma unroll 1
@@ -301,7 +307,6 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     lds_barrier();
     {
         const int colg = nh * 32 + r31;
-        const float bz = bias ? bias[colg] : 0.f;
         float v[8];
         if (kh) {
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
                 const int rr = kh * 8 + 2 * jq + t;
                 const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
                 const uint64_t flat = (uint64_t)((tile0 + row) * 64 + colg);
-                const uint64_t z = act_hash64(act.seed, (uint64_t)act.step[0], flat >> 2);
+                const uint64_t z = act_hash64(act.seed, drop_step, flat >> 2);
                 mylo[t] = (uint32_t)z; myhi[t] = (uint32_t)(z >> 32);
             }
 #define QOT_ZSHARE(S)                                                                                   \

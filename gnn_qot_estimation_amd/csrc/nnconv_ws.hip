@@ -11,9 +11,10 @@
 //     weights h_e (edge MLP hidden vector, mean scale) sit beside them, and every lane forms its own
 //     MFMA A operand  A[i, k*64 + c] = sum_e h_e[k] x_{j(e)}[c]  with D-ish FMAs in the shadow of the
 //     MFMAs.  Gather and multiply are one phase instead of two serialised ones.
-//   * lane (row r = lane & 31, half h = lane >> 5) of wave w covers k in [80w + 40h, 80w + 40h + 40)
-//     in blocks of 8 (one slab, 8 consecutive channels = two ds_read_b128 of the source row per edge);
-//     both 32-column halves are multiplied from the same A value (2 MFMAs per A value).
+//   * lane (row r = lane & 31, half h = lane >> 5) of wave w covers channels [8w, 8w+8) of slabs
+//     [5h, 5h+5): per in-edge ONE 32-B piece of the source row (two ds_read_b128) and the edge's 5 slab
+//     weights give 40 operand values; both 32-column halves are multiplied from the same value
+//     (2 MFMAs per value, 80 per wave and tile).
 //   * LDS image of a source row: 16 x 16-B chunks, chunk q of slot s at position q ^ (s & 15)
 //     (the swizzle is applied on the DMA's per-lane SOURCE address; destination is lane-linear).
 //   * tiles whose in-edge count exceeds the staging capacity run extra rounds (A is linear in the
@@ -123,13 +124,18 @@ __device__ __forceinline__ void ws_meta_l2(WsMeta<D>& m, const WsTile& T, int lo
     if (TRANSPOSE) m.sc = invdeg[m.src];
 }
 
+// Weight row of a slot (kWsHW = 12 floats): slab s sits at (s / SH) * 6 + s % SH with SH = (K+2)/2 slabs per
+// lane half, so a lane reads its half's weights as two ds_read_b64 + one ds_read_b32 at an 8-B aligned offset.
+__device__ __forceinline__ int ws_wpos(int s, int SH) { return (s / SH) * 6 + s % SH; }
+
 // edge-MLP hidden vector h = relu(W1 ea + b1) (x the adjoint's mean scale) -> LDS, with the slot's source row.
-// own != 0: also describe the 32 destinations' own rows (root slab) in slots kWsEC..kWsEC+31
+// own != 0: also the 32 destinations' own rows (root slab; their rows are added outside the edge loop) in
+// slots kWsEC..kWsEC+31, and the tile's row pointers
 template <int D>
 __device__ __forceinline__ void ws_meta_write(const WsMeta<D>& m, const WsTile& T, int lo, int own, int64_t N,
                                               const float (&w1r)[2 * D * D], const float (&b1r)[2 * D],
                                               float* __restrict__ hb, int* __restrict__ rp, int* __restrict__ srcbuf) {
-    constexpr int K = 2 * D;
+    constexpr int K = 2 * D, SH = (K + 2) / 2;
     const int t = threadIdx.x;
     const int cnt = T.ne - lo < kWsEC ? T.ne - lo : kWsEC;
     if (t < cnt) {
@@ -138,18 +144,14 @@ __device__ __forceinline__ void ws_meta_write(const WsMeta<D>& m, const WsTile& 
             float hv = b1r[kk];
 #pragma unroll
             for (int d = 0; d < D; ++d) hv = fmaf(w1r[kk * D + d], m.ee[d], hv);
-            hb[t * kWsHW + kk] = fmaxf(hv, 0.f) * m.sc;
+            hb[t * kWsHW + ws_wpos(kk, SH)] = fmaxf(hv, 0.f) * m.sc;
         }
-        hb[t * kWsHW + K] = m.sc;
-        hb[t * kWsHW + K + 1] = 0.f;
+        hb[t * kWsHW + ws_wpos(K, SH)] = m.sc;
+        hb[t * kWsHW + ws_wpos(K + 1, SH)] = 0.f;
         srcbuf[t] = m.src;
     } else if (own && t >= kWsEC && t < kWsSlots) {
         const int64_t ii = T.tile0 + (t - kWsEC);
-        const bool ok = T.valid && ii < N;
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk) hb[t * kWsHW + kk] = 0.f;
-        hb[t * kWsHW + K + 1] = ok ? 1.0f : 0.f;
-        srcbuf[t] = ok ? (int)ii : 0;
+        srcbuf[t] = (T.valid && ii < N) ? (int)ii : 0;
     }
     if (own && t < 33) rp[t] = T.valid ? m.rp - T.e0 : 0;
 }
@@ -187,11 +189,10 @@ __device__ __forceinline__ void ws_dma_rows(float* __restrict__ xb, const int* _
 }
 
 struct WsLane {           // a lane's (= destination row's) slice of the staged round
-    int beg, deg, n_it, maxit, ownslot;
-    float inv;
+    int beg, deg, maxdeg, ownslot;
 };
 
-__device__ __forceinline__ WsLane ws_lane_params(const int* __restrict__ rp, int lo, int own, float inv) {
+__device__ __forceinline__ WsLane ws_lane_params(const int* __restrict__ rp, int lo) {
     const int r = threadIdx.x & 31;
     WsLane L;
     int beg = rp[r] - lo, end = rp[r + 1] - lo;
@@ -199,51 +200,90 @@ __device__ __forceinline__ WsLane ws_lane_params(const int* __restrict__ rp, int
     end = end > kWsEC ? kWsEC : end;
     L.beg = beg;
     L.deg = end > beg ? end - beg : 0;
-    L.n_it = L.deg + (own ? 1 : 0);
-    int maxit = L.n_it;
+    int m = L.deg;
 #pragma unroll
     for (int off = 32; off; off >>= 1) {
-        const int o = __shfl_xor(maxit, off);
-        maxit = o > maxit ? o : maxit;
+        const int o = __shfl_xor(m, off);
+        m = o > m ? o : m;
     }
-    L.maxit = __builtin_amdgcn_readfirstlane(maxit);
+    L.maxdeg = __builtin_amdgcn_readfirstlane(m);
     L.ownslot = kWsEC + r;
-    L.inv = inv;
     return L;
 }
 
-// One block: 8 k-steps per lane half (one slab, 8 consecutive channels), 16 MFMAs.
-__device__ __forceinline__ void ws_block(const float4* __restrict__ xb4, const float* __restrict__ hb, const WsLane& L,
-                                         int kk0, const float (&w)[8][2], f32x16& c0, f32x16& c1) {
-    const int slab = kk0 >> 6, cq = (kk0 & 63) >> 2;
-    float4 a0 = f4zero(), a1 = f4zero();
+// Operand values of this lane: a[j][i] = sum_e w_e[slab j of my half] * x_{src(e)}[8 wave + i].
+// Two edges in flight; a lane past its own degree reads its own row with the all-zero weight row kWsEC.
+template <int SH>
+__device__ __forceinline__ void ws_operands(const float4* __restrict__ xb4, const float* __restrict__ hb,
+                                            const WsLane& L, float (&a)[SH][8]) {
+    const int cq = 2 * (threadIdx.x >> 6), hoff = ((threadIdx.x >> 5) & 1) * 6;
 #pragma unroll 1
-    for (int d0 = 0; d0 < L.maxit; d0 += 4) {      // 4 edges in flight: 4 weight reads + 8 row reads, then 32 FMAs
-        float wv[4];
-        float4 xa[4], xc[4];
+    for (int d0 = 0; d0 < L.maxdeg; d0 += 2) {
+        float wv[2][SH + 1];
+        float4 xa[2], xc[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int d = d0 + u;
-            const bool isedge = d < L.deg;
-            const int slot = isedge ? L.beg + d : L.ownslot;
-            const float wr = hb[slot * kWsHW + slab];
-            wv[u] = d < L.n_it ? (isedge ? wr * L.inv : wr) : 0.f;
-            const int pos = cq ^ (slot & 15);
-            xa[u] = xb4[slot * 16 + pos];
-            xc[u] = xb4[slot * 16 + (pos ^ 1)];
+            const bool live = d < L.deg;
+            const int xslot = live ? L.beg + d : L.ownslot;
+            const int wrow = live ? L.beg + d : kWsEC;
+            const float2* wp = reinterpret_cast<const float2*>(hb + wrow * kWsHW + hoff);
+#pragma unroll
+            for (int j = 0; j < (SH + 1) / 2; ++j) {
+                if (2 * j + 1 < SH) {
+                    const float2 w2 = wp[j];
+                    wv[u][2 * j] = w2.x; wv[u][2 * j + 1] = w2.y;
+                } else {
+                    wv[u][2 * j] = hb[wrow * kWsHW + hoff + 2 * j];
+                }
+            }
+            const int pos = cq ^ (xslot & 15);
+            xa[u] = xb4[xslot * 16 + pos];
+            xc[u] = xb4[xslot * 16 + (pos ^ 1)];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a0 = fma4(wv[u], xa[u], a0);
-            a1 = fma4(wv[u], xc[u], a1);
-        }
-    }
-    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], w[i][0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], w[i][1], c1, 0, 0, 0);
+            for (int j = 0; j < SH; ++j) {
+                a[j][0] = fmaf(wv[u][j], xa[u].x, a[j][0]); a[j][1] = fmaf(wv[u][j], xa[u].y, a[j][1]);
+                a[j][2] = fmaf(wv[u][j], xa[u].z, a[j][2]); a[j][3] = fmaf(wv[u][j], xa[u].w, a[j][3]);
+                a[j][4] = fmaf(wv[u][j], xc[u].x, a[j][4]); a[j][5] = fmaf(wv[u][j], xc[u].y, a[j][5]);
+                a[j][6] = fmaf(wv[u][j], xc[u].z, a[j][6]); a[j][7] = fmaf(wv[u][j], xc[u].w, a[j][7]);
+            }
     }
+}
+
+// mean scale of the forward form, then the destination's own row into the root slab (last slab of the upper half)
+template <int SH, bool TRANSPOSE>
+__device__ __forceinline__ void ws_finish_operands(const float4* __restrict__ xb4, const WsLane& L, float inv, bool own,
+                                                   float (&a)[SH][8]) {
+    if (!TRANSPOSE) {
+#pragma unroll
+        for (int j = 0; j < SH; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[j][i] *= inv;
+    }
+    if (own) {
+        const int cq = 2 * (threadIdx.x >> 6);
+        const float sel = ((threadIdx.x >> 5) & 1) ? 1.0f : 0.f;
+        const int pos = cq ^ (L.ownslot & 15);
+        const float4 xa = xb4[L.ownslot * 16 + pos], xc = xb4[L.ownslot * 16 + (pos ^ 1)];
+        a[SH - 1][0] = fmaf(sel, xa.x, a[SH - 1][0]); a[SH - 1][1] = fmaf(sel, xa.y, a[SH - 1][1]);
+        a[SH - 1][2] = fmaf(sel, xa.z, a[SH - 1][2]); a[SH - 1][3] = fmaf(sel, xa.w, a[SH - 1][3]);
+        a[SH - 1][4] = fmaf(sel, xc.x, a[SH - 1][4]); a[SH - 1][5] = fmaf(sel, xc.y, a[SH - 1][5]);
+        a[SH - 1][6] = fmaf(sel, xc.z, a[SH - 1][6]); a[SH - 1][7] = fmaf(sel, xc.w, a[SH - 1][7]);
+    }
+}
+
+template <int SH, int J0, int J1>
+__device__ __forceinline__ void ws_mfma(const float (&a)[SH][8], const float (&w)[SH][8][2], f32x16& c0, f32x16& c1) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][i], w[j][i][0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][i], w[j][i][1], c1, 0, 0, 0);
+        }
 }
 
 // K-eighths of a finished tile: [wave][row][64] partials in LDS -> bias / activation -> 256-B row stores
@@ -278,28 +318,27 @@ __device__ __forceinline__ void ws_epilogue(const float4* __restrict__ red4, int
 
 // Software pipeline over the workgroup's tiles A (multiplying), B (rows in flight), C (metadata in flight):
 //   top      rows(A) + meta(A) + meta(B) in LDS, partial sums of the previous tile in the other row buffer
-//   1  issue C's index loads            2  block 0 of A            3  previous tile's epilogue (LDS sums, stores)
-//   4  issue C's edge-feature loads     5  barrier; DMA rows(B) into the buffer the epilogue just drained
-//   6  blocks 1.. of A (+ extra rounds when A has more in-edges than slots)
-//   7  barrier; C's metadata -> LDS, A's partial sums -> A's row buffer; wait for rows(B); barrier
+//   1  issue C's index loads            2  A's operand values (edge loop over LDS)    3  first 16 MFMAs
+//   4  previous tile's epilogue (LDS sums, stores)          5  issue C's edge-feature loads
+//   6  barrier: the other row buffer is drained and nobody reads A's rows any more;  DMA rows(B) into it
+//   7  the other 64 MFMAs (+ extra rounds when A has more in-edges than slots)
+//   8  C's metadata -> LDS, A's partial sums -> A's row buffer; wait for rows(B); barrier
 template <int D, bool TRANSPOSE, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
     const float* __restrict__ b1, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, const float* __restrict__ Wp,
     const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act) {
-    constexpr int K = 2 * D, S = K + 2, KT = S * 64;
-    constexpr int NBLK = KT / 128;          // blocks of 8 k-steps per lane half
+    constexpr int K = 2 * D, S = K + 2, KT = S * 64, SH = S / 2;
     constexpr int GT = KT / 8;              // Wp groups (8 k values each) per column half
-    static_assert(S <= kWsHW, "weight row too narrow");
+    static_assert(SH <= 5, "weight row holds 2 x 5 slabs (+ pad)");
     static_assert(kWsSlots * 64 >= 8 * 32 * 64, "row buffer doubles as the K-eighth exchange");
     __shared__ __attribute__((aligned(16))) float xbuf[2][kWsSlots * 64];
     __shared__ __attribute__((aligned(16))) float hbuf[2][kWsSlots * kWsHW];
-    __shared__ int srcbuf[kWsSlots];
+    __shared__ int srcbuf[2][kWsSlots];
     __shared__ int rpbuf[2][36];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
-    const int base_kk = wave * (KT / 8) + h * (KT / 16);
     const int64_t ntiles = (N + 31) / 32;
 
     WsTile A = ws_tile_uniform(ws_tile_info(0, ntiles, N, rowptr));
@@ -314,31 +353,31 @@ __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
 #pragma unroll
     for (int q = 0; q < K; ++q) b1r[q] = b1[q];
 
-    // resident weights: wreg[b][i][nh] = Wcat[base_kk + 8b + i][32 nh + r]   (Wp: see qot_nnconv_fused)
-    float wreg[NBLK][8][2];
+    // resident weights: wreg[j][i][nh] = Wcat[(h SH + j) 64 + 8 wave + i][32 nh + r]   (Wp: see qot_nnconv_fused)
+    float wreg[SH][8][2];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b)
+    for (int j = 0; j < SH; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
-                const int g = (base_kk >> 3) + b;
-                wreg[b][i][nh] = Wp[(((int64_t)nh * GT + g) * 64 + (i & 1) * 32 + r) * 4 + (i >> 1)];
+                const int g = (h * SH + j) * 8 + wave;
+                wreg[j][i][nh] = Wp[(((int64_t)nh * GT + g) * 64 + (i & 1) * 32 + r) * 4 + (i >> 1)];
             }
     const float4 bias4 = bias ? ld4(bias + 4 * (t & 15)) : f4zero();
     const uint64_t drop_step = (act.enabled && act.thr16) ? (uint64_t)act.step[0] : 0;
+    if (t < 2 * kWsHW) hbuf[t / kWsHW][kWsEC * kWsHW + t % kWsHW] = 0.f;      // the all-zero weight rows
 
     // ---- prologue: A staged synchronously, B's metadata behind it
     WsMeta<D> m;
     ws_meta_l1<D, TRANSPOSE>(m, A, 0, N, rowptr, col, eidx);
     ws_meta_l2<D, TRANSPOSE>(m, A, 0, ea, invdeg);
-    ws_meta_write<D>(m, A, 0, 1, N, w1r, b1r, hbuf[0], rpbuf[0], srcbuf);
+    ws_meta_write<D>(m, A, 0, 1, N, w1r, b1r, hbuf[0], rpbuf[0], srcbuf[0]);
     ws_lds_barrier();
-    ws_dma_rows(xbuf[0], srcbuf, A.ne < kWsEC ? A.ne : kWsEC, 1, x, ldx);
+    ws_dma_rows(xbuf[0], srcbuf[0], A.ne < kWsEC ? A.ne : kWsEC, 1, x, ldx);
     ws_meta_l1<D, TRANSPOSE>(m, B, 0, N, rowptr, col, eidx);
     ws_meta_l2<D, TRANSPOSE>(m, B, 0, ea, invdeg);
-    ws_lds_barrier();                              // srcbuf(A) consumed by every wave's DMA issue
-    ws_meta_write<D>(m, B, 0, 1, N, w1r, b1r, hbuf[1], rpbuf[1], srcbuf);
+    ws_meta_write<D>(m, B, 0, 1, N, w1r, b1r, hbuf[1], rpbuf[1], srcbuf[1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ws_lds_barrier();
 
@@ -352,43 +391,54 @@ __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
     for (int64_t it = 0;; ++it) {
         const WsTile Dn = ws_tile_info(it + 3, ntiles, N, rowptr);
         const float4* xb4 = reinterpret_cast<const float4*>(xbuf[p]);
-        const float* hb = hbuf[p];
         f32x16 c0, c1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { c0[j] = 0.f; c1[j] = 0.f; }
         const float inv_next = TRANSPOSE ? 1.0f : invdeg[(B.valid && B.tile0 + r < N) ? B.tile0 + r : 0];
+
         ws_meta_l1<D, TRANSPOSE>(m, C, 0, N, rowptr, col, eidx);                      // 1
-        WsLane L = ws_lane_params(rpbuf[p], 0, 1, inv);
-        ws_block(xb4, hb, L, base_kk, wreg[0], c0, c1);                              // 2
+        float a[SH][8];
+#pragma unroll
+        for (int j = 0; j < SH; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[j][i] = 0.f;
+        {
+            const WsLane L = ws_lane_params(rpbuf[p], 0);
+            ws_operands<SH>(xb4, hbuf[p], L, a);                                     // 2
+            ws_finish_operands<SH, TRANSPOSE>(xb4, L, inv, true, a);
+        }
         QOT_WS_STAMP(0)
-        if (have_prev)                                                               // 3
+        ws_mfma<SH, 0, 1>(a, wreg, c0, c1);                                          // 3
+        if (have_prev)                                                               // 4
             ws_epilogue(reinterpret_cast<const float4*>(xbuf[p ^ 1]), prev_tile0, bias4, act, drop_step, out, N);
         QOT_WS_STAMP(1)
-        ws_meta_l2<D, TRANSPOSE>(m, C, 0, ea, invdeg);                                // 4
-        ws_lds_barrier();                                                            // 5
-        if (B.valid) ws_dma_rows(xbuf[p ^ 1], srcbuf, B.ne < kWsEC ? B.ne : kWsEC, 1, x, ldx);
+        ws_meta_l2<D, TRANSPOSE>(m, C, 0, ea, invdeg);                                // 5
+        ws_lds_barrier();                                                            // 6
         QOT_WS_STAMP(2)
-#pragma unroll
-        for (int b = 1; b < NBLK; ++b) ws_block(xb4, hb, L, base_kk + 8 * b, wreg[b], c0, c1);   // 6
+        if (B.valid) ws_dma_rows(xbuf[p ^ 1], srcbuf[p ^ 1], B.ne < kWsEC ? B.ne : kWsEC, 1, x, ldx);
+        ws_mfma<SH, 1, SH>(a, wreg, c0, c1);                                         // 7
         QOT_WS_STAMP(3)
 #pragma unroll 1
         for (int lo = kWsEC; lo < A.ne; lo += kWsEC) {       // rare: more in-edges than slots
             WsMeta<D> mx;
-            ws_lds_barrier();
             ws_meta_l1<D, TRANSPOSE>(mx, A, lo, N, rowptr, col, eidx);
             ws_meta_l2<D, TRANSPOSE>(mx, A, lo, ea, invdeg);
-            ws_meta_write<D>(mx, A, lo, 0, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf);
+            ws_meta_write<D>(mx, A, lo, 0, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf[p]);
             ws_lds_barrier();
-            ws_dma_rows(xbuf[p], srcbuf, A.ne - lo < kWsEC ? A.ne - lo : kWsEC, 0, x, ldx);
+            ws_dma_rows(xbuf[p], srcbuf[p], A.ne - lo < kWsEC ? A.ne - lo : kWsEC, 0, x, ldx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ws_lds_barrier();
-            const WsLane Lx = ws_lane_params(rpbuf[p], lo, 0, inv);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) ws_block(xb4, hb, Lx, base_kk + 8 * b, wreg[b], c0, c1);
+            for (int j = 0; j < SH; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[j][i] = 0.f;
+            const WsLane Lx = ws_lane_params(rpbuf[p], lo);
+            ws_operands<SH>(xb4, hbuf[p], Lx, a);
+            ws_finish_operands<SH, TRANSPOSE>(xb4, Lx, inv, false, a);
+            ws_lds_barrier();                                // before the next round / the partial sums overwrite the rows
+            ws_mfma<SH, 0, SH>(a, wreg, c0, c1);
         }
-        ws_lds_barrier();                                                            // 7
-        QOT_WS_STAMP(4)
-        ws_meta_write<D>(m, C, 0, 1, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf);
+        ws_meta_write<D>(m, C, 0, 1, N, w1r, b1r, hbuf[p], rpbuf[p], srcbuf[p]);     // 8
         {
             float* red = xbuf[p];
 #pragma unroll
@@ -398,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_ws64_kernel(
                 red[(wave * 32 + row) * 64 + 32 + r] = c1[j];
             }
         }
+        QOT_WS_STAMP(4)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QOT_WS_STAMP(5)
         ws_lds_barrier();

@@ -572,3 +572,79 @@ def test_table_mode_detected_for_batches_without_hint(cuda_device):
     y2 = c(p2)
     assert p2.uniform_node_ids is None and "tmaps" not in p2._qot_cache
     assert y2.shape == ya.shape
+
+
+def _nnconv_fp64(x, ea, w1, b1, wcat, bias, rowptr, col, eids, invdeg, transpose):
+    """out = bias + A @ Wcat in fp64 from the walked index (CSR forward / CSC adjoint), App. B.2 algebra."""
+    x, ea, w1, b1, wcat, bias, invdeg = (t.double().cpu() for t in (x, ea, w1, b1, wcat, bias, invdeg))
+    rowptr = rowptr.cpu().long()
+    nE = int(rowptr[-1])                           # the index buffers may be longer than the walked range
+    col, eids = col.cpu().long()[:nE], eids.cpu().long()[:nE]
+    N, H = x.shape
+    K = w1.shape[0]
+    rows = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
+    A = torch.zeros(N, (K + 2) * H, dtype=torch.float64)
+    if col.numel():
+        h = torch.relu(ea[eids] @ w1.t() + b1)                       # [E, K]
+        sc = invdeg[col] if transpose else invdeg[rows]
+        hw = torch.cat([h, torch.ones(len(col), 1, dtype=torch.float64)], 1) * sc[:, None]
+        contrib = (hw[:, :, None] * x[col][:, None, :]).reshape(len(col), (K + 1) * H)
+        A[:, :(K + 1) * H].index_add_(0, rows, contrib)
+    A[:, (K + 1) * H:] = x
+    return A @ wcat + bias
+
+
+@pytest.mark.parametrize("case", ["random", "hub", "edge_dim2", "no_edges"])
+def test_weight_stationary_nnconv_matches_tile_kernel_and_fp64(cuda_device, case):
+    """csrc/nnconv_ws.hip (experimental dataflow: weights in registers, rows by LDS-DMA, operands formed on
+    the fly) against the production tile kernel and an fp64 restatement; `hub` has more in-edges in one
+    32-row tile than staging slots (extra rounds), `no_edges` exercises the clamped index loads."""
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd.functional import nnconv_perm_index
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    P = _lib.ptr
+    dev = cuda_device
+    g = torch.Generator().manual_seed(5)
+    H, D = 64, (2 if case == "edge_dim2" else 4)
+    K = 2 * D
+    if case == "hub":
+        N = 1000 + 13
+        src = torch.randint(0, N, (700,), generator=g)
+        ei = torch.cat([torch.stack([src, torch.full_like(src, 40)]),            # node 40: in-degree 700
+                        torch.randint(0, N, (2, 3000), generator=g)], 1)
+    elif case == "no_edges":
+        N, ei = 70, torch.zeros(2, 0, dtype=torch.long)
+    else:
+        N = 777
+        ei = torch.randint(0, N, (2, 4 * N), generator=g)
+    E = ei.shape[1]
+    ei = ei.to(dev)
+    gi = build_graph_index(ei, N)
+    x = torch.randn(N, H, generator=g).to(dev)
+    ea = torch.rand(max(E, 1), D, generator=g).to(dev)
+    w1 = torch.randn(K, D, generator=g).to(dev); b1 = torch.randn(K, generator=g).to(dev)
+    wcat = (torch.randn((K + 2) * H, H, generator=g) / 8).to(dev)
+    bias = torch.randn(H, generator=g).to(dev)
+    wp = wcat.reshape(-1)[nnconv_perm_index((K + 2) * H, dev)].contiguous()
+    for transpose, (rp, col, eids) in ((0, (gi.rowptr, gi.col, gi.eid)), (1, (gi.rowptr_t, gi.col_t, gi.eid_t))):
+        ref = _nnconv_fp64(x, ea, w1, b1, wcat, bias, rp, col, eids, gi.invdeg, transpose)
+        outs = []
+        for name in ("qot_nnconv_fused", "qot_nnconv_fused_ws"):
+            out = torch.full((N, H), float("nan"), device=dev)
+            _lib.call(name, P(x), H, P(ea), P(w1), P(b1), P(rp), P(col), P(eids), P(gi.invdeg), transpose, P(wp),
+                      P(bias), P(out), N, H, D, 0, 0.0, 0.0, 0, None)
+            torch.cuda.synchronize()
+            assert rel_err(out.double().cpu(), ref) <= TOL, (case, transpose, name)
+            outs.append(out)
+        assert rel_err(outs[1], outs[0]) <= TOL
+    # identical dropout masks and activation epilogue (counter-based draws keyed by element index)
+    step = torch.tensor([3], dtype=torch.int64, device=dev)
+    outs = []
+    for name in ("qot_nnconv_fused", "qot_nnconv_fused_ws"):
+        out = torch.empty(N, H, device=dev)
+        _lib.call(name, P(x), H, P(ea), P(w1), P(b1), P(gi.rowptr), P(gi.col), P(gi.eid), P(gi.invdeg), 0, P(wp),
+                  P(bias), P(out), N, H, D, 1, 0.01, 0.25, 1234, P(step))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert bool(((outs[0] == 0) == (outs[1] == 0)).all())
+    assert rel_err(outs[1], outs[0]) <= TOL

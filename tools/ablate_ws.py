@@ -34,7 +34,7 @@ lib.qot_debug_ws_stamps(None, 1); run("qot_nnconv_fused_ws", out2); torch.cuda.s
 buf = (ctypes.c_ulonglong * 8)(); lib.qot_debug_ws_stamps(ctypes.cast(buf, ctypes.c_void_p), 0)
 lib.qot_debug_ws_stamps(None, 2)
 tiles = (N + 31) // 32
-names = ["index loads + block 0", "previous epilogue", "feature loads + barrier + dma issue", "blocks 1..", "barrier", "meta/partials to LDS + dma wait", "barrier"]
+names = ["index loads + operands", "16 MFMAs + previous epilogue", "feature loads + barrier", "dma issue + 64 MFMAs", "meta/partials to LDS", "dma wait", "barrier"]
 tot = sum(buf[:7])
 for n, v in zip(names, buf[:7]):
     print(f"  {n:28s} {v / (tiles * 8):9.0f} ticks/wave/tile  {100.0 * v / tot:5.1f}%")
