@@ -425,6 +425,13 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         const int64_t tile = xcd_tile(it, ntiles);
         if (tile < 0) break;
         const int64_t tile0 = tile * 32;
+        // the tile's own x rows are requested BEFORE the gather and written to LDS behind it (loaded behind the
+        // gather, as first written, the load was one exposed memory round trip per tile)
+        float4 xown;
+        {
+            const int64_t j = tile0 + (threadIdx.x >> 4);
+            xown = (j < N) ? ld4(xf + j * ldx + 4 * (threadIdx.x & 15)) : f4zero();
+        }
         // ---- gather: 16 lanes per source node j (float4 = 64 channels), out-edges over the CSC
         {
             const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
@@ -496,9 +503,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         // part of what pushed this kernel into scratch.
         {
             const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
-            const int64_t j = tile0 + il;
-            const float4 v = (j < N) ? ld4(xf + j * ldx + 4 * sub) : f4zero();
-            *reinterpret_cast<float4*>(&xs[il * 64 + 4 * sub]) = v;
+            *reinterpret_cast<float4*>(&xs[il * 64 + 4 * sub]) = xown;
         }
         // WcatT fragments: two buffers used alternately, two chunks per trip of a rolled loop.  Written as
         // `bc = bn` copies the compiler put `s_waitcnt vmcnt(0)` at the top of every chunk, i.e. waited for
