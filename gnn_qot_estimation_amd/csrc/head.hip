@@ -171,11 +171,36 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     if (t < O) part[H * H + H + O * H + t] = ab3;
 }
 
-__global__ void head_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
-    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (t >= n) return;
-    const float s = wave_sum_partials(partials, nblk, n, t);
-    if ((threadIdx.x & 63) == 0) out[t] = s;
+// out[t] = sum over the nblk workgroup partials (fixed order).  1024 threads = 64 consecutive outputs x 16 part
+// groups: every load is a 256-B row segment (the one-wave-per-output form read each partial with a stride of
+// n floats: 12.8 us for 9 MB), 8 independent loads in flight per thread, part groups meet in LDS.
+__global__ __launch_bounds__(1024) void head_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n,
+                                                                float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + o;
+    float acc = 0.f;
+    if (t < n) {
+        const int per = (nblk + 15) / 16;
+        const int p0 = sg * per, p1 = (p0 + per < nblk) ? p0 + per : nblk;
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(int64_t)(p + u) * n + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; p < p1; ++p) acc += partials[(int64_t)p * n + t];
+    }
+    red[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && t < n) {
+        float s = red[0][o];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) s += red[q][o];
+        out[t] = s;
+    }
 }
 
 }  // namespace qot
@@ -227,7 +252,7 @@ extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const fl
                                                                   workspace, B, O, ap, x_in, in_ap));
     QOT_LAUNCH_CHECK();
     const int n = H * H + H + O * H + O + (x_in ? H : 0);
-    head_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, blocks, n, grads);
+    head_partial_sum_kernel<<<grid_for(n, 64), 1024, 0, stream>>>(workspace, blocks, n, grads);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }
