@@ -91,12 +91,17 @@ class TrainStep:
         # SmoothL1Loss value + gradient from one kernel, then backward from the model output
         _, g = QF.smooth_l1_loss_and_grad(out, self.y, loss_out=self.loss)
         out.backward(g)
-        self.flat.gather_grads()             # one kernel packs all gradients into the flat buffer
+        if self.world > 1:
+            self.flat.gather_grads()         # one kernel packs all gradients into the flat buffer RCCL reduces
+
+    def _update(self):
+        # one rank: the pack rides in the update kernel (gradients read from their own tensors)
+        self.opt.step(grads=True if self.world == 1 else None)
 
     def _eager(self):
         self._fwd_bwd()
         self.flat.all_reduce_grads()
-        self.opt.step()
+        self._update()
 
     def capture(self):
         """Capture forward+backward and the optimizer update as two HIP graphs; the RCCL
@@ -112,13 +117,13 @@ class TrainStep:
         if self.world == 1:                  # no exchange step: the optimizer rides in the same graph
             with torch.cuda.graph(self.graph_fb):
                 self._fwd_bwd()
-                self.opt.step()
+                self._update()
             return
         with torch.cuda.graph(self.graph_fb):
             self._fwd_bwd()
         self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_opt):
-            self.opt.step()
+            self._update()
 
     def __call__(self):
         if self.graph_fb is None:

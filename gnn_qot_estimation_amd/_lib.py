@@ -76,6 +76,7 @@ SIGNATURES = {
     "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p]),
     "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p]),
     "qot_sgd_momentum": (_int, [_p, _p, _p, _i64, _f, _f, _int, _p]),
+    "qot_sgd_momentum_multi": (_int, [_p, _p, _p, _int, _p, _p, _i64, _f, _p, _f, _int, _p]),
     "qot_sgd_momentum_dev": (_int, [_p, _p, _p, _i64, _p, _f, _int, _p]),
     "qot_small_gemm": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _int, _int, _int, _int, _int, _p]),
     "qot_colsum_workspace_floats": (_sz, [_int]),

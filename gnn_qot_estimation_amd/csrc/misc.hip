@@ -289,6 +289,34 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     p[t] = fmaf(-lr, b, p[t]);
 }
 
+// The same update reading the gradient of every parameter from its own tensor (pointers by value in the
+// kernel arguments): the pack into the flat gradient buffer -- one more launch per step -- rides along (the
+// packed value is still written, so the flat buffer stays what an all-reduce or a test would read).
+constexpr int kSgdMaxSegs = 48;
+struct SgdSegs {
+    const float* g[kSgdMaxSegs];
+    int64_t off[kSgdMaxSegs + 1];
+    int count;
+};
+__global__ void sgd_momentum_multi_kernel(float* __restrict__ p, SgdSegs segs, float* __restrict__ gflat,
+                                          float* __restrict__ buf, int64_t n, float lr, float mu, int first,
+                                          const float* __restrict__ lr_dev) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (lr_dev) lr = lr_dev[0];
+    int lo = 0, hi = segs.count;               // segment with off[lo] <= t < off[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (segs.off[mid] <= t) lo = mid; else hi = mid;
+    }
+    const float* gp = segs.g[lo];
+    const float g = gp ? gp[t - segs.off[lo]] : 0.f;
+    if (gflat) gflat[t] = g;
+    const float b = first ? g : fmaf(mu, buf[t], g);
+    buf[t] = b;
+    p[t] = fmaf(-lr, b, p[t]);
+}
+
 // column sums of a row-major [N, C] matrix (bias gradients), optionally fused with the backward of
 // dropout(leaky_relu(.)): gx = g * act'(y) is written and ITS column sums are produced -- the bias
 // gradient of a conv whose epilogue carried the activation.  Block partials, then one wave per column
@@ -504,6 +532,29 @@ extern "C" int qot_sgd_momentum(float* param, const float* grad, float* momentum
                                                                   nullptr);
         QOT_LAUNCH_CHECK();
     }
+    return QOT_OK;
+}
+
+extern "C" int qot_sgd_momentum_multi(float* param, const float* const* grads, const int64_t* offsets, int count,
+                                      float* grad_flat, float* momentum_buf, int64_t n, float lr,
+                                      const float* lr_dev, float momentum, int first_step, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || count < 0 || (n > 0 && (!param || !momentum_buf || !grads || !offsets))) return QOT_ERR_BADARG;
+    if (count > kSgdMaxSegs) return QOT_ERR_UNSUPPORTED;
+    if (n == 0 || count == 0) return QOT_OK;
+    SgdSegs segs;
+    for (int i = 0; i < count; ++i) {
+        if (offsets[i] < 0 || offsets[i + 1] < offsets[i]) return QOT_ERR_BADARG;
+        segs.g[i] = grads[i];
+        segs.off[i] = offsets[i];
+    }
+    if (offsets[0] != 0 || offsets[count] != n) return QOT_ERR_BADARG;
+    segs.off[count] = n;
+    for (int i = count; i < kSgdMaxSegs; ++i) { segs.g[i] = nullptr; segs.off[i + 1] = n; }
+    segs.count = count;
+    sgd_momentum_multi_kernel<<<grid_for(n, 256), 256, 0, stream>>>(param, segs, grad_flat, momentum_buf, n, lr, momentum,
+                                                                    first_step, lr_dev);
+    QOT_LAUNCH_CHECK();
     return QOT_OK;
 }
 

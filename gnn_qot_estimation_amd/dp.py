@@ -114,10 +114,42 @@ class FusedSGD:
         if self.lr_dev is not None:
             self.lr_dev.fill_(self._lr)
 
-    def step(self):
+    def step(self, grads=None):
+        """One update from ``flat.flat_grad``.  ``grads`` (one tensor or ``None`` per parameter, in
+        ``flat.params`` order; ``True`` = each parameter's ``.grad``) folds ``FlatModel.gather_grads`` into the
+        update kernel: every gradient is read from its own tensor and the packed copy is still written to
+        ``flat.flat_grad`` -- one launch instead of two when no all-reduce sits between backward and update."""
         from . import _lib
         if not self.flat.flat_param.is_cuda:
             raise _lib.QotError("FusedSGD runs on the GPU only (use torch.optim.SGD on CPU)")
+        if grads is not None and len(self.flat.params) <= 48:
+            import ctypes
+            params = self.flat.params
+            if grads is True:
+                grads = [p.grad for p in params]
+            keep, ptrs, offs, off = [], [], [0], 0
+            for p, g in zip(params, grads):
+                if g is not None:
+                    if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != p.numel() or g.device != p.device:
+                        g = g.to(device=p.device, dtype=torch.float32).contiguous()
+                    keep.append(g)
+                ptrs.append(None if g is None else g.data_ptr())
+                off += p.numel()
+                offs.append(off)
+            n = len(params)
+            parr = (ctypes.c_void_p * n)(*ptrs)
+            oarr = (ctypes.c_int64 * (n + 1))(*offs)
+            _lib.call("qot_sgd_momentum_multi", _lib.ptr(self.flat.flat_param), ctypes.addressof(parr),
+                      ctypes.addressof(oarr), n, _lib.ptr(self.flat.flat_grad), _lib.ptr(self.buf), self.flat.numel,
+                      self.lr, None if self.lr_dev is None else _lib.ptr(self.lr_dev), self.momentum,
+                      int(self.steps == 0))
+            self.steps += 1
+            return
+        if grads is not None:
+            if grads is True:
+                grads = [p.grad for p in self.flat.params]
+            torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1)
+                       for g, p in zip(grads, self.flat.params)], out=self.flat.flat_grad)
         if self.lr_dev is not None:
             _lib.call("qot_sgd_momentum_dev", _lib.ptr(self.flat.flat_param), _lib.ptr(self.flat.flat_grad),
                       _lib.ptr(self.buf), self.flat.numel, _lib.ptr(self.lr_dev), self.momentum, int(self.steps == 0))

@@ -195,9 +195,7 @@ class StepReplayer:
             out, y = fwd(functional, data, self.out_dim)
             _, g = QF.smooth_l1_loss_and_grad(out, y, loss_out=self._loss)
             grads = torch.autograd.grad(out, list(leaves.values()), g, allow_unused=True)
-            torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
-                       for gr, p in zip(grads, self.flat.params)], out=self.flat.flat_grad)
-            self.opt.step()
+            self.opt.step(grads=list(grads))     # the pack into the flat gradient rides in the update kernel
         else:
             with torch.no_grad():
                 out, y = fwd(self.model, data, self.out_dim)

@@ -300,6 +300,14 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
  * Both take qot_colsum_workspace_floats(C) floats of workspace. */
 int qot_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                      float momentum, int first_step, qot_stream_t stream);
+/* The same update with the gradient pack folded in: parameter i's gradient is read from grads[i]
+ * (device pointer, NULL = zero gradient; `grads` and `offsets` are HOST arrays of `count` pointers and
+ * count+1 element offsets into the flat buffers, offsets[0] = 0, offsets[count] = n, count <= 48), the
+ * packed value is also stored to grad_flat (may be NULL).  lr_dev != NULL: learning rate read from device
+ * memory (as qot_sgd_momentum_dev), else `lr`.  Replaces FlatModel.gather_grads' concatenation launch. */
+int qot_sgd_momentum_multi(float* param, const float* const* grads, const int64_t* offsets, int count,
+                           float* grad_flat, float* momentum_buf, int64_t n, float lr, const float* lr_dev,
+                           float momentum, int first_step, qot_stream_t stream);
 /* same update with the learning rate read from device memory at run time, so that a step captured in a
  * HIP graph follows the scheduler (StepLR, topological_training/train.py:67,181) without re-capture */
 int qot_sgd_momentum_dev(float* param, const float* grad, float* momentum_buf, int64_t n, const float* lr_dev,

@@ -231,6 +231,37 @@ def test_fused_sgd_matches_torch_sgd(cuda_device):
         assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("device_lr", [False, True])
+def test_fused_sgd_with_folded_gradient_pack(cuda_device, device_lr):
+    """FusedSGD.step(grads=True): gradients read from the parameters' own .grad tensors (one unused
+    parameter -> None), packed copy still written to flat_grad; == torch.optim.SGD for 3 steps."""
+    from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.unused, self.b = torch.nn.Linear(8, 16), torch.nn.Linear(3, 5), torch.nn.Linear(16, 4)
+
+        def forward(self, x):
+            return self.b(self.a(x))
+
+    torch.manual_seed(0)
+    a = M().to(cuda_device)
+    b = copy.deepcopy(a)
+    flat = FlatModel(a)
+    fused = FusedSGD(flat, lr=0.1, momentum=0.9, device_lr=device_lr)
+    ref = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9)
+    for step in range(3):
+        x = torch.randn(32, 8, device=cuda_device)
+        flat.detach_grads(); ref.zero_grad()
+        a(x).square().mean().backward(); b(x).square().mean().backward()
+        fused.step(grads=True); ref.step()
+        packed = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in a.parameters()])
+        assert torch.equal(flat.flat_grad, packed)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+
+
 def test_colsum(cuda_device):
     from gnn_qot_estimation_amd.functional import colsum
     x = torch.randn(10007, 256, device=cuda_device)
