@@ -25,7 +25,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 2          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 3          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -90,7 +90,7 @@ SIGNATURES = {
     "qot_act_bwd_colsum": (_int, [_p, _p, _p, _i64, _int, _f, _f, _u64, _p, _p, _p, _p]),
     "qot_smooth_l1_workspace_floats": (_sz, []),
     "qot_smooth_l1": (_int, [_p, _p, _i64, _f, _p, _p, _p, _p]),
-    "qot_table_project_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
+    "qot_table_project_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p, _p, _p]),
     "qot_table_project_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _p]),
     "qot_table_maps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "qot_step_advance": (_int, [_p, _p, _p]),

@@ -55,9 +55,15 @@ struct Proj4 {
 // out[v, s*H + o] = b_s[o] + sum_a table[v, a] * w_s[o, a];  one block per table row, 4H threads
 template <int H>
 __global__ __launch_bounds__(4 * H) void table_project_fwd_kernel(const float* __restrict__ table, Proj4 p,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, int64_t* __restrict__ counter,
+                                                                  int64_t* __restrict__ snapshot) {
     __shared__ float row[H];
     const int v = blockIdx.x, c = threadIdx.x;
+    if (counter && v == 0 && c == 0) {        // as step_advance_kernel: this is the forward's first launch in table mode
+        const int64_t cc = counter[0] + 1;
+        counter[0] = cc;
+        snapshot[0] = cc;
+    }
     if (c < H) row[c] = table[(int64_t)v * H + c];
     __syncthreads();
     const int s = c / H, o = c % H;
@@ -200,12 +206,14 @@ extern "C" int qot_smooth_l1(const float* pred, const float* target, int64_t n, 
 
 extern "C" int qot_table_project_fwd(const float* table, const float* wq, const float* bq, const float* wk,
                                      const float* bk, const float* wv, const float* bv, const float* ws,
-                                     const float* bs, float* out, int V, int H, qot_stream_t stream) {
-    if (V < 0) return QOT_ERR_BADARG;
-    if (V == 0) return QOT_OK;
+                                     const float* bs, float* out, int V, int H, int64_t* step_counter,
+                                     int64_t* step_snapshot, qot_stream_t stream) {
+    if (V < 0 || (step_counter && !step_snapshot)) return QOT_ERR_BADARG;
+    if (V == 0) return step_counter ? qot_step_advance(step_counter, step_snapshot, stream) : QOT_OK;
     if (!table || !wq || !bq || !wk || !bk || !wv || !bv || !ws || !bs || !out) return QOT_ERR_BADARG;
     Proj4 p{{wq, wk, wv, ws}, {bq, bk, bv, bs}};
-    QOT_TABLE_H(H, table_project_fwd_kernel<kH><<<V, 4 * kH, 0, (hipStream_t)stream>>>(table, p, out));
+    QOT_TABLE_H(H, table_project_fwd_kernel<kH><<<V, 4 * kH, 0, (hipStream_t)stream>>>(table, p, out, step_counter,
+                                                                                       step_snapshot));
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

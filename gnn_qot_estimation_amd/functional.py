@@ -165,13 +165,16 @@ class TableProjectFn(torch.autograd.Function):
     parameters in place (one launch; backward one launch for all nine gradients)."""
 
     @staticmethod
-    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs):
+    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs, step_pair=None):
+        """``step_pair = (counter, snapshot)``: the launch also advances the dropout step counter (it is the
+        forward's first kernel in table mode; see ``qot_table_project_fwd``)."""
         require_cuda(table, wq, bq, wk, bk, wv, bv, ws, bs)
         table, wq, bq, wk, bk, wv, bv, ws, bs = (_f32c(t) for t in (table, wq, bq, wk, bk, wv, bv, ws, bs))
         V, H = table.shape
         out = torch.empty(V, 4 * H, dtype=torch.float32, device=table.device)
+        cnt, snap = step_pair if step_pair is not None else (None, None)
         _lib.call("qot_table_project_fwd", P(table), P(wq), P(bq), P(wk), P(bk), P(wv), P(bv), P(ws), P(bs), P(out),
-                  V, H)
+                  V, H, P(cnt), P(snap))
         ctx.save_for_backward(table, wq, wk, wv, ws)
         return out
 
@@ -186,7 +189,7 @@ class TableProjectFn(torch.autograd.Function):
         gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
         _lib.call("qot_table_project_bwd", P(g), P(table), P(wq), P(wk), P(wv), P(ws), P(gt), P(gw), P(gb), V, H)
         return (gt, gw[:H], gb[:H], gw[H:2 * H], gb[H:2 * H], gw[2 * H:3 * H], gb[2 * H:3 * H], gw[3 * H:],
-                gb[3 * H:])
+                gb[3 * H:], None)
 
 
 _LOSS_WS = {}

@@ -61,12 +61,13 @@ class TransformerConv(nn.Module):
         qkvs = QF.LinearFn.apply(x, w, b)             # one MFMA GEMM for q|k|v|skip
         return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph, None, act)
 
-    def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None):
+    def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None, step_pair=None):
         """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
-        ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows."""
+        ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows.
+        ``step_pair``: see ``QF.TableProjectFn``."""
         t4 = QF.TableProjectFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
                                      self.lin_key.bias, self.lin_value.weight, self.lin_value.bias,
-                                     self.lin_skip.weight, self.lin_skip.bias)      # [V, 4H]
+                                     self.lin_skip.weight, self.lin_skip.bias, step_pair)      # [V, 4H]
         return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps, act)
 
 

@@ -66,12 +66,16 @@ class TopologicalGNN(nn.Module):
         else:
             n = x.shape[0]
             graph = graph_index_for(data, n)
-        step = None
+        step, step_pair = None, None
         if self.training and self.dropout.p > 0.0:
             step = torch.empty_like(self._qot_step)      # this forward's draw; backward re-reads it
-            _lib.call("qot_step_advance", _lib.ptr(self._qot_step), _lib.ptr(step))
+            if maps is not None:                         # table mode: the projection launch advances the counter
+                step_pair = (self._qot_step, step)
+            else:
+                _lib.call("qot_step_advance", _lib.ptr(self._qot_step), _lib.ptr(step))
         if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
-            x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step))
+            x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step),
+                                         step_pair=step_pair)
         else:
             x = self.conv1(x, edge_index, edge_attr, graph=graph, act=self._act(0, step))
         l0, l3 = self.mlp[0], self.mlp[3]

@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 2
+#define QOT_ABI_VERSION 3
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -354,10 +354,12 @@ int qot_smooth_l1(const float* pred, const float* target, int64_t n, float beta,
 /* ---- embedding-table projection for TransformerConv table mode: out[V,4H] = [q|k|v|skip] rows of
  * table[V,H] under lin_query/lin_key/lin_value/lin_skip (topological_training/models.py:51-53 with
  * x = node_embeddings(node_ids)); reads the four Linear parameters in place.
+ * step_counter != NULL: the launch also performs qot_step_advance(step_counter, step_snapshot) -- in table
+ * mode it is the forward's first kernel, and the dropout counter's own launch was ~5 us of a 0.6 ms step.
  * bwd: grad_table[V,H], grad_w[4H,H] and grad_b[4H] in q|k|v|skip order. */
 int qot_table_project_fwd(const float* table, const float* wq, const float* bq, const float* wk, const float* bk,
                           const float* wv, const float* bv, const float* ws, const float* bs, float* out, int V,
-                          int H, qot_stream_t stream);
+                          int H, int64_t* step_counter, int64_t* step_snapshot, qot_stream_t stream);
 int qot_table_project_bwd(const float* grad_out, const float* table, const float* wq, const float* wk,
                           const float* wv, const float* ws, float* grad_table, float* grad_w, float* grad_b, int V,
                           int H, qot_stream_t stream);
