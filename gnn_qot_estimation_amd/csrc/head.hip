@@ -82,15 +82,23 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) aw3[e] = 0.f;
     const int t = threadIdx.x;
+    // both weight matrices sit in LDS for the whole kernel: read from global memory inside the graph loop the
+    // 64-step matrix-vector product below was 64 dependent L2 round trips per graph
+    __shared__ float w0s[H * H];
+    __shared__ float w3s[8 * H];
+    for (int e = t; e < H * H; e += 256) w0s[e] = w0[e];
+    for (int e = t; e < O * H; e += 256) w3s[e] = w3[e];
     // gW0 element e of thread t: row o = (t*PER + e) / H, col a = (t*PER + e) % H
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         if (t < O) go[t] = gout[b * O + t];
         if (t < H) pp[t] = pooled[b * H + t];
+        const int beg = ptr[b], end = ptr[b + 1];       // requested here, used by the pool backward below
+        const float hv_pre = (t < H) ? hidden[b * H + t] : 0.f;
         __syncthreads();
         if (t < H) {
             float v = 0.f;
-            for (int o = 0; o < O; ++o) v = fmaf(w3[o * H + t], go[o], v);
-            const float hv = hidden[b * H + t];
+            for (int o = 0; o < O; ++o) v = fmaf(w3s[o * H + t], go[o], v);
+            const float hv = hv_pre;
             // d/dpre of dropout(leaky_relu(pre)): hidden == 0 <=> dropped (or pre == 0)
             float d = 0.f;
             if (act.thr16) {
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         if (t < H) {
             float v = 0.f;
 #pragma unroll 8
-            for (int o = 0; o < H; ++o) v = fmaf(w0[o * H + t], gh[o], v);
+            for (int o = 0; o < H; ++o) v = fmaf(w0s[o * H + t], gh[o], v);
             gp[t] = v;
         }
 #pragma unroll
@@ -121,7 +129,6 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         }
         __syncthreads();
         // pool backward: every node row of the graph gets gp / count
-        const int beg = ptr[b], end = ptr[b + 1];
         const float inv = 1.0f / (float)((end - beg) > 1 ? (end - beg) : 1);
         constexpr int TPR = H / 4, RPB = 256 / TPR;
         const int sub = t % TPR, slot = t / TPR;
