@@ -679,3 +679,22 @@ def test_weight_stationary_nnconv_matches_tile_kernel_and_fp64(cuda_device, case
     torch.cuda.synchronize()
     assert bool(((outs[0] == 0) == (outs[1] == 0)).all())
     assert rel_err(outs[1], outs[0]) <= TOL
+
+
+@pytest.mark.parametrize("B,C", [(3, 64), (16, 260), (64, 25600), (100, 1028), (1024, 512), (1500, 128)])
+def test_rowsum_wide_all_row_counts(cuda_device, B, C):
+    """qot_rowsum_wide (table-gradient sum over graph groups): direct, one-launch (16 <= B <= 1024) and
+    two-launch forms against an fp64 sum; fixed summation order -> bitwise repeatable."""
+    from gnn_qot_estimation_amd import _lib
+    P = _lib.ptr
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, generator=g).to(cuda_device)
+    outs = []
+    for _ in range(2):
+        out = torch.full((C,), float("nan"), device=cuda_device)
+        ws = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(C), dtype=torch.float32, device=cuda_device)
+        _lib.call("qot_rowsum_wide", P(x), B, C, P(out), P(ws))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], x.double().sum(0)) <= 1e-5
