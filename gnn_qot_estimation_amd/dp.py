@@ -77,6 +77,14 @@ class FlatModel:
             return
         world = dist.get_world_size(group)
         if weight is None:
+            # RCCL averages inside the collective (ncclAvg): no separate division launch.  gloo has no AVG;
+            # a backend that rejects the op does so when it is enqueued, before anything is exchanged.
+            if self.flat_grad.is_cuda and getattr(FlatModel, "_avg_ok", True) and dist.get_backend(group) == "nccl":
+                try:
+                    dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)
+                    return
+                except (RuntimeError, ValueError):
+                    FlatModel._avg_ok = False
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.div_(world)
         else:

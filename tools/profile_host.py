@@ -41,4 +41,4 @@ for _ in range(n):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumulative").print_stats("gnn_qot_estimation_amd|built-in|method", 45)
