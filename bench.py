@@ -268,8 +268,37 @@ def cpu_baseline(sample_graphs):
                        f"host has {ncpu} cores), torch {torch.__version__} CPU")
 
 
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per device) from a
+    parent that never touches the GPU, relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torch.cuda call has happened in this process: the children are fresh processes, nothing is re-exec'ed
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -319,6 +348,13 @@ def main():
     loss = float(step.loss.item())
     if not (loss == loss) or loss in (float("inf"), float("-inf")):
         raise SystemExit(f"non-finite loss {loss}")
+    # the exchange step alone (outside the timed region): events around the flat-gradient all-reduce
+    all_reduce_us = None
+    if world > 1:
+        all_reduce_us = event_time_ms(step.flat.all_reduce_grads, iters=20, warm=3) * 1e3
+        t = torch.tensor([all_reduce_us], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_us = float(t.item())
 
     if rank == 0:
         graphs = CFG["B"] * world * args.steps
@@ -332,7 +368,11 @@ def main():
                                    "SGD momentum 0.9, SmoothL1; " + ("graph index cached across steps (BENCH_PREP_OUTSIDE: the HBM-resident, cached-batch loader mode; not the headline)" if os.environ.get("BENCH_PREP_OUTSIDE") else "CSR build included in every step"),
                        "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world,
                        "launch": "eager" if step.graph_fb is None else "hip-graph replay (fwd+bwd, optimizer)",
-                       "parallelism": f"dp{world}", "final_loss": loss},
+                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "collective_world_size": dist.get_world_size() if world > 1 else 1,
+                       "collective_backend": dist.get_backend() if world > 1 else None,
+                       "all_reduce_us": all_reduce_us,
+                       "all_reduce_floats": int(step.flat.flat_grad.numel())},
         }
         rows = kernel_table(model, batch)
         dom = max(rows, key=lambda r: r["ms"])

@@ -20,6 +20,36 @@ import torch
 import torch.distributed as dist
 
 
+_REDUCE_MODE = {}
+
+
+def _probe_avg(like: torch.Tensor, group=None) -> int:
+    if not (like.is_cuda and dist.get_backend(group) == "nccl"):
+        return 0
+    try:
+        probe = torch.ones(1, dtype=like.dtype, device=like.device)
+        dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+        return 1
+    except (RuntimeError, ValueError):
+        return 0
+
+
+def reduce_mode(like: torch.Tensor, group=None) -> str:
+    """``"avg"`` when every rank of ``group`` can run ``ReduceOp.AVG`` on tensors like ``like`` (RCCL), else
+    ``"sum"`` (gloo has no AVG: sum, then divide).  Decided once per (group, device type): each rank probes the
+    op on a scratch tensor -- a backend that rejects it does so when the call is enqueued, before anything is
+    exchanged -- and the outcomes are combined with a MIN all-reduce, so all ranks agree even if one build
+    differs.  The AVG branch is unverified at world > 1 until a multi-GPU run exists."""
+    key = (id(group) if group is not None else 0, like.device.type)
+    mode = _REDUCE_MODE.get(key)
+    if mode is None:
+        ok = _probe_avg(like, group)
+        flag = torch.tensor([ok], dtype=torch.int32, device=like.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        mode = _REDUCE_MODE[key] = "avg" if int(flag.item()) == 1 else "sum"
+    return mode
+
+
 class FlatModel:
     def __init__(self, model: torch.nn.Module):
         self.model = model
@@ -77,16 +107,14 @@ class FlatModel:
             return
         world = dist.get_world_size(group)
         if weight is None:
-            # RCCL averages inside the collective (ncclAvg): no separate division launch.  gloo has no AVG;
-            # a backend that rejects the op does so when it is enqueued, before anything is exchanged.
-            if self.flat_grad.is_cuda and getattr(FlatModel, "_avg_ok", True) and dist.get_backend(group) == "nccl":
-                try:
-                    dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)
-                    return
-                except (RuntimeError, ValueError):
-                    FlatModel._avg_ok = False
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
-            self.flat_grad.div_(world)
+            # RCCL averages inside the collective (ncclAvg): no separate division launch.  Whether the
+            # group's backend takes the op is decided ONCE per group, collectively (``reduce_mode``), so
+            # every rank issues the same collective on every step.
+            if reduce_mode(self.flat_grad, group) == "avg":
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+                self.flat_grad.div_(world)
         else:
             w = weight.to(self.flat_grad.dtype).reshape(1)
             buf = torch.cat([self.flat_grad * w, w])

@@ -104,3 +104,37 @@ def test_factorised_nnconv_identity():
     A = torch.cat(blocks, dim=1)
     out = A @ nnconv_wcat(enn[2].weight, enn[2].bias, m.lin.weight, h, h, 2 * d) + m.bias
     assert rel_err(out, ref) <= 1e-5
+
+
+def test_topological_three_layers_sparse_vs_dense64():
+    """``num_layers=3`` (cfg4/cfg5 architecture): TransformerConv + NNConv + NNConv."""
+    torch.manual_seed(0)
+    m = O.TopologicalGNN(12, 8, 3, 4, dropout_p=0.0, num_layers=3).eval()
+    with torch.no_grad():
+        m.conv3.bias.uniform_(-0.3, 0.3)
+    b = _topo_batch()
+    ref = D64.topological_forward(m.state_dict(), b, extra_nnconv=("conv3.",))
+    assert rel_err(m(b), ref) <= 1e-5
+    # the default still is the 2-layer reference model, same keys as before
+    assert [k for k in O.TopologicalGNN(12, 8, 3, 4).state_dict() if k.startswith("conv3")] == []
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_lightpath_three_layers_sparse_vs_dense64(train):
+    """``num_layers=3`` (cfg3 architecture): 3 x (GATConv(heads=4) + BatchNorm + relu)."""
+    torch.manual_seed(0)
+    m = O.LightpathGNN(5, 4, 3, 1, dropout_p=0.0, num_layers=3)
+    with torch.no_grad():
+        for l in (1, 2, 3):
+            getattr(m, f"conv{l}").bias.uniform_(-0.5, 0.5)
+            bn = getattr(m, f"norm{l}").module
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    b = S.lightpath_batch(6)
+    m.train(train)
+    out, lb = m(b)
+    ref, lb64 = D64.lightpath_forward(sd0, b, 1, train_stats=train,
+                                      extra_layers=(("conv2.", "norm2.module."), ("conv3.", "norm3.module.")))
+    assert torch.equal(lb, lb64)
+    assert rel_err(out, ref) <= 2e-5
