@@ -143,15 +143,16 @@ def _rank_world():
     return 0, 1
 
 
-def _local_indices(idx: range, batch_size: int, rank: int, world: int) -> List[int]:
-    """Every global batch of ``batch_size`` graphs is cut into contiguous per-rank ranges."""
-    if world == 1:
-        return list(idx)
-    out: List[int] = []
+def _local_batches(idx: Sequence[int], batch_size: int, rank: int, world: int) -> List[List[int]]:
+    """One entry per GLOBAL batch of ``batch_size`` graphs: this rank's contiguous share of it (possibly empty
+    when a trailing batch holds fewer graphs than there are ranks).  Every rank gets the same number of
+    entries, so every rank issues the same sequence of collectives, and a step is the single-process step
+    over the same global batch."""
+    out: List[List[int]] = []
     for b0 in range(0, len(idx), batch_size):
         n = min(batch_size, len(idx) - b0)
         lo, hi = graph_range(n, rank, world)
-        out.extend(idx[b0 + lo:b0 + hi])
+        out.append(list(idx[b0 + lo:b0 + hi]))
     return out
 
 
@@ -238,12 +239,11 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     """One pass over ``indices``; trains when ``opt`` is given, else evaluates under ``no_grad``."""
     fwd = _KINDS[kind]
     rank, world = _rank_world()
-    local_bs = max(1, batch_size // world)
     # an HBM-resident shard keeps its batch objects (and the graph index the model attaches to them):
     # the chunks repeat every few epochs, so later visits do no graph preparation at all
     resident = isinstance(dataset, PackedGraphs) and dataset.device is not None
-    loader = GraphLoader(dataset, local_bs, shuffle=False, device=device,
-                         indices=_local_indices(indices, batch_size, rank, world), cache_batches=resident)
+    loader = GraphLoader(dataset, batch_size, shuffle=False, device=device, cache_batches=resident,
+                         batches=_local_batches(indices, batch_size, rank, world))
     stats = RegressionStats(out_dim, device)
     skipped = 0
     training = opt is not None
@@ -258,19 +258,52 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
         res["avg_loss"] = res["loss_sum"] / max(len(indices), 1)
         res["skipped"] = skipped
         return res
+    coupled = world > 1 and training          # ranks meet in collectives inside every step
     with torch.set_grad_enabled(training):
         for data in loader:
             if training:
                 flat.zero_grad()
-            if world > 1 and kind == "lightpath":
-                # ranks are coupled inside forward/backward (global BatchNorm statistics): a batch
-                # is skipped by all ranks or by none (one flag all-reduce, one host read per batch)
-                lut_col = getattr(model, "is_lut_index", None)
-                has = (data.x[:, lut_col] == 1.0).any().to(torch.int32).reshape(1)
-                dist.all_reduce(has, op=dist.ReduceOp.MIN)
-                if int(has.item()) == 0:
-                    skipped += data.num_graphs
+            if data is None and not coupled:
+                continue
+            if coupled and kind == "lightpath":
+                # Ranks are coupled inside forward/backward (global BatchNorm statistics), and whether a batch
+                # is skipped is a property of the GLOBAL batch, as in the single-process reference: skipped only
+                # when NO rank holds a LUT node.  One flag all-reduce (one host read) per batch.
+                has = 0
+                if data is not None:
+                    has = int(bool((data.x[:, getattr(model, "is_lut_index", None)] == 1.0).any()))
+                flags = torch.tensor([has, int(data is None)], dtype=torch.int32, device=device)
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+                any_lut, any_empty = (int(v) for v in flags.tolist())
+                if any_empty:
+                    # fewer graphs than ranks in a trailing batch: a rank without nodes cannot take part in the
+                    # BatchNorm exchange; all ranks skip it (documented deviation, at most world-1 graphs per epoch)
+                    skipped += 0 if data is None else data.num_graphs
                     continue
+                model.allow_empty_lut = True
+                try:
+                    if not any_lut:
+                        # the reference raises AFTER conv1/norm1 ran (models.py:30-36): running statistics move
+                        with torch.no_grad():
+                            fwd(model, data, out_dim)
+                        skipped += data.num_graphs
+                        continue
+                    out, y = fwd(model, data, out_dim)
+                finally:
+                    model.allow_empty_lut = False
+                loss = criterion(out, y) if y.shape[0] else out.sum() * 0.0
+                (loss * loss_scale(y.shape[0], device)).backward()
+                flat.all_reduce_grads()
+                opt.step()
+                if y.shape[0]:
+                    stats.update(y, out, loss)
+                continue
+            if data is None:
+                # empty share of a trailing batch: zero contribution, same collectives as the other ranks
+                loss_scale(0, device)
+                flat.all_reduce_grads()
+                opt.step()
+                continue
             try:
                 out, y = fwd(model, data, out_dim)
             except ValueError:
@@ -290,6 +323,10 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     res = stats.result()
     # the reference divides by len(loader.dataset), skipped graphs included (train.py:119)
     res["avg_loss"] = res["loss_sum"] / max(len(indices), 1)
+    if world > 1:
+        sk = torch.tensor([skipped], dtype=torch.int64, device=device)
+        dist.all_reduce(sk, op=dist.ReduceOp.SUM)
+        skipped = int(sk.item())
     res["skipped"] = skipped
     return res
 
@@ -357,10 +394,12 @@ def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: s
     stats = RegressionStats(output_dim, device)
     model.eval()
     rank, world = _rank_world()
-    loader = GraphLoader(dataset, max(1, batch_size // world), shuffle=False, device=device,
-                         indices=_local_indices(idx, batch_size, rank, world))
+    loader = GraphLoader(dataset, batch_size, shuffle=False, device=device,
+                         batches=_local_batches(idx, batch_size, rank, world))
     with torch.no_grad():
         for data in loader:
+            if data is None:
+                continue
             try:
                 out, y = fwd(model, data, output_dim)
             except ValueError:

@@ -264,10 +264,14 @@ class GraphLoader:
 
     def __init__(self, dataset: Sequence[Data], batch_size: int, shuffle: bool = False, drop_last: bool = False,
                  device="cuda", depth: int = 2, generator: Optional[torch.Generator] = None,
-                 indices: Optional[Sequence[int]] = None, cache_batches: bool = False):
+                 indices: Optional[Sequence[int]] = None, cache_batches: bool = False,
+                 batches: Optional[Sequence[Sequence[int]]] = None):
         """``indices`` restricts the loader to a subset of ``dataset`` (the role of
         ``torch.utils.data.Subset`` at ``topological_training/train.py:34-36,89``) without wrapping
-        it, so a pinned ``PackedGraphs`` keeps its zero-collate path for consecutive ranges."""
+        it, so a pinned ``PackedGraphs`` keeps its zero-collate path for consecutive ranges.
+        ``batches`` gives the batches explicitly (one index list per yielded batch, in order; an EMPTY
+        list yields ``None``): a data-parallel rank uses it to take its share of every global batch, so
+        that all ranks iterate the same number of steps (``harness.run_epoch``)."""
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
@@ -275,6 +279,7 @@ class GraphLoader:
         self.generator = generator
         self.indices = None if indices is None else list(indices)
         self.cache_batches = cache_batches
+        self.batches = None if batches is None else [list(b) for b in batches]
         self.cuda = self.device.type == "cuda"
         self.depth = max(2, depth) if self.cuda else 1
         self._stages = [_Staging(self.device, pin=True) for _ in range(self.depth)] if self.cuda else []
@@ -285,6 +290,8 @@ class GraphLoader:
         return len(self.dataset) if self.indices is None else len(self.indices)
 
     def __len__(self) -> int:
+        if self.batches is not None:
+            return len(self.batches)
         n = self.num_samples
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
@@ -328,29 +335,35 @@ class GraphLoader:
         return dev
 
     def __iter__(self):
-        order = self._order()
-        chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
-        if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
-            chunks.pop()
+        if self.batches is not None:
+            chunks = self.batches
+        else:
+            order = self._order()
+            chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+            if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
+                chunks.pop()
+        consecutive = lambda c: len(c) == 0 or list(c) == list(range(c[0], c[0] + len(c)))
         resident = isinstance(self.dataset, PackedGraphs) and self.dataset.device is not None
-        if resident and all(list(c) == list(range(c[0], c[0] + len(c))) for c in chunks):
+        if resident and all(consecutive(c) for c in chunks):
             # HBM-resident shard, consecutive graphs: batches are views of it (nothing to stage)
             for c in chunks:
-                yield self.dataset.device_batch(c[0], c[0] + len(c), cache=self.cache_batches)
+                yield self.dataset.device_batch(c[0], c[0] + len(c), cache=self.cache_batches) if c else None
             return
         if not self.cuda:
             for c in chunks:
-                yield self._stage(c, 0)
+                yield self._stage(c, 0) if c else None
             return
         pending = []
         nxt = 0
+        stage = lambda k: self._stage(chunks[k], k % self.depth) if chunks[k] else None
         for _ in range(min(self.depth - 1, len(chunks))):      # prime the pipeline
-            pending.append(self._stage(chunks[nxt], nxt % self.depth))
+            pending.append(stage(nxt))
             nxt += 1
         while pending:
             cur = pending.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(cur._qot_ready)   # device-side wait only
+            if cur is not None:
+                torch.cuda.current_stream(self.device).wait_event(cur._qot_ready)   # device-side wait only
             if nxt < len(chunks):
-                pending.append(self._stage(chunks[nxt], nxt % self.depth))
+                pending.append(stage(nxt))
                 nxt += 1
             yield cur

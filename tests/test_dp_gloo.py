@@ -96,3 +96,73 @@ def test_flat_model_keeps_state_dict_and_single_leaf():
     flat.flat_grad.fill_(1.0)
     opt.step()
     assert torch.allclose(m.conv2.bias, before["conv2.bias"] - 0.5)   # views follow the fused update
+
+
+# --------------------------------------------------------------------------- harness.run_epoch with world > 1
+class _TorchSGD:
+    """``run_epoch`` only calls ``opt.step()``; on the CPU the fused HIP update is replaced by torch's."""
+
+    def __init__(self, flat, lr, momentum):
+        self.inner = torch.optim.SGD([flat.leaf], lr=lr, momentum=momentum)
+
+    def step(self):
+        self.inner.step()
+
+
+def _epoch_setup(total):
+    from gnn_qot_estimation_amd import synthetic as S
+    from oracle import sparse as O
+    import gnn_qot_estimation_amd as q
+    torch.manual_seed(0)
+    graphs = []
+    for g in range(total):
+        b = S.topological_batch(2, 1, n=10, e=24, first_graph=g)
+        graphs.append(q.Data(edge_index=b.edge_index, edge_attr=b.edge_attr, node_ids=b.node_ids, num_nodes=10, y=b.y))
+    model = O.TopologicalGNN(10, 8, 3, 4, dropout_p=0.0)
+    return graphs, model
+
+
+def _epoch_worker(rank, world, port, total, n_idx, bs, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from gnn_qot_estimation_amd import harness as Hn
+        from gnn_qot_estimation_amd.dp import FlatModel
+        graphs, model = _epoch_setup(total)
+        flat = FlatModel(model)
+        flat.broadcast_params()
+        opt = _TorchSGD(flat, 0.1, 0.9)
+        res = Hn.run_epoch(model, graphs, range(n_idx), kind="topological", batch_size=bs, out_dim=3, device="cpu",
+                           criterion=torch.nn.SmoothL1Loss(), flat=flat, opt=opt)
+        ev = Hn.run_epoch(model, graphs, range(n_idx), kind="topological", batch_size=bs, out_dim=3, device="cpu",
+                          criterion=torch.nn.SmoothL1Loss())
+        ret[rank] = dict(param=flat.flat_param.clone(), loss=res["avg_loss"], n=res["n"], r2=res["r2"], ev=ev["avg_loss"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_idx,bs", [(2, 21, 5), (3, 23, 7)])
+def test_run_epoch_ranks_stay_in_step_and_match_single_process(world, n_idx, bs):
+    """ADVICE r1 (harness.py:241): len(indices) % batch_size in {1, world-1}, batch_size not divisible by the
+    world size, a trailing batch smaller than the world size -- no hang, and the epoch equals the 1-rank epoch."""
+    assert n_idx % bs in (1, world - 1) and bs % world != 0
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_epoch_worker, args=(world, _free_port(), 24, n_idx, bs, ret), nprocs=world, join=True)
+        got = dict(ret)
+    from gnn_qot_estimation_amd import harness as Hn
+    from gnn_qot_estimation_amd.dp import FlatModel
+    graphs, model = _epoch_setup(24)
+    flat = FlatModel(model)
+    opt = _TorchSGD(flat, 0.1, 0.9)
+    one = Hn.run_epoch(model, graphs, range(n_idx), kind="topological", batch_size=bs, out_dim=3, device="cpu",
+                       criterion=torch.nn.SmoothL1Loss(), flat=flat, opt=opt)
+    ev = Hn.run_epoch(model, graphs, range(n_idx), kind="topological", batch_size=bs, out_dim=3, device="cpu",
+                      criterion=torch.nn.SmoothL1Loss())
+    for r in range(world):
+        assert torch.allclose(got[r]["param"], flat.flat_param, rtol=1e-4, atol=1e-6), r
+        assert got[r]["n"] == one["n"] == n_idx
+        # the per-rank loss sums weight every rank's local mean by its row count -> the global sum
+        assert abs(got[r]["loss"] - one["avg_loss"]) < 1e-5 and abs(got[r]["ev"] - ev["avg_loss"]) < 1e-5
+        assert abs(got[r]["r2"] - one["r2"]) < 1e-4

@@ -45,12 +45,18 @@ def test_streaming_stats_match_sklearn():
     assert Hn.RegressionStats(3, "cpu").result()["n"] == 0
 
 
-def test_local_indices_partition_each_global_batch():
-    idx = range(100, 100 + 23)
-    parts = [Hn._local_indices(idx, 8, r, 3) for r in range(3)]
-    assert sorted(sum(parts, [])) == list(idx)
-    # first global batch = graphs 100..107 cut 2/3/3
-    assert parts[0][:2] == [100, 101] and parts[1][:3] == [102, 103, 104] and parts[2][:3] == [105, 106, 107]
+def test_local_batches_give_every_rank_one_entry_per_global_batch():
+    """per-rank batch counts must not diverge (world=3, bs=512, 2048 graphs gave [4,5,5])."""
+    for total, bs, world in ((2048, 512, 3), (1539, 512, 8), (23, 8, 3), (21, 5, 2), (7, 4, 8)):
+        idx = range(100, 100 + total)
+        parts = [Hn._local_batches(idx, bs, r, world) for r in range(world)]
+        nb = (total + bs - 1) // bs
+        assert all(len(p) == nb for p in parts)
+        for b in range(nb):        # the union of the ranks' shares of batch b IS global batch b, in order
+            assert sum((p[b] for p in parts), []) == list(idx[b * bs:(b + 1) * bs])
+    parts = [Hn._local_batches(range(100, 123), 8, r, 3) for r in range(3)]
+    assert parts[0][0] == [100, 101] and parts[1][0] == [102, 103, 104] and parts[2][0] == [105, 106, 107]
+    assert Hn._local_batches(range(21), 5, 0, 2)[-1] == []          # trailing batch of one graph: rank 0 is empty
 
 
 def test_checkpoint_dictionary_round_trip(tmp_path):
