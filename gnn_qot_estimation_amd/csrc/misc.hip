@@ -17,6 +17,20 @@ __global__ void rows_gather_kernel(const float* __restrict__ src, const int32_t*
     st4(out + r * C4 * 4 + c, ld4(src + (int64_t)idx[r] * C4 * 4 + c));
 }
 
+// Embedding lookup: as rows_gather, but ids outside [0, V) are clamped so that a bad id can never read past the
+// table (the Python layer raises IndexError like nn.Embedding before it gets here; this is the memory-safety net
+// for direct C-ABI callers).
+__device__ __forceinline__ int clamp_id(int id, int V) { return id < 0 ? 0 : (id >= V ? V - 1 : id); }
+
+__global__ void embed_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                    float* __restrict__ out, int64_t n, int C4, int V) {
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * C4) return;
+    int64_t r = t / C4;
+    int c = (int)(t - r * C4) * 4;
+    st4(out + r * C4 * 4 + c, ld4(src + (int64_t)clamp_id(idx[r], V) * C4 * 4 + c));
+}
+
 __global__ void rows_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                     float* __restrict__ out, int64_t n, int C4) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -47,8 +61,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         int64_t r = r0 + t / H;
         int c = (int)(t % H);
         float val = g[r * H + c];
-        if (LDS_TABLE) atomicAdd(&tab[ids[r] * H + c], val);
-        else atomicAdd(&gt[(int64_t)ids[r] * H + c], val);
+        const int id = clamp_id(ids[r], V);
+        if (LDS_TABLE) atomicAdd(&tab[id * H + c], val);
+        else atomicAdd(&gt[(int64_t)id * H + c], val);
     }
     if (LDS_TABLE) {
         __syncthreads();
@@ -623,8 +638,8 @@ extern "C" int qot_embed_fwd(const float* table, const int32_t* ids, float* out,
                              qot_stream_t stream) {
     if (N < 0 || (H & 3) || H <= 0) return (H & 3) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
-    if (!table || !ids || !out) return QOT_ERR_BADARG;
-    rows_gather_kernel<<<grid_for(N * (H / 4), 256), 256, 0, (hipStream_t)stream>>>(table, ids, out, N, H / 4);
+    if (!table || !ids || !out || V <= 0) return QOT_ERR_BADARG;
+    embed_gather_kernel<<<grid_for(N * (H / 4), 256), 256, 0, (hipStream_t)stream>>>(table, ids, out, N, H / 4, V);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

@@ -178,7 +178,8 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t it, int64_t ntiles) {
     return (local < chunk && t < ntiles) ? t : -1;
 }
 
-// diagnostic build only (VARIANT 3): per-phase cycle sums, one adder per wave
+// diagnostic build only (make DIAG=1, VARIANT 3): per-phase cycle sums, one adder per wave
+#ifdef QOT_DIAG
 __device__ unsigned long long g_stamps[8];
 #define QOT_STAMP(slot)                                                              \
     if (VARIANT == 3) {                                                              \
@@ -186,6 +187,9 @@ __device__ unsigned long long g_stamps[8];
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[slot], _t - t_prev);        \
         t_prev = _t;                                                                 \
     }
+#else
+#define QOT_STAMP(slot)
+#endif
 
 template <int D, bool TRANSPOSE, int VARIANT = 0>
 __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
@@ -868,6 +872,7 @@ static int num_cus() {
     return n;
 }
 
+#ifdef QOT_DIAG
 extern "C" int qot_nnconv_fused_ws(const float* x, int ld_x, const float* edge_attr, const float* w1,
                                    const float* b1, const int32_t* rowptr, const int32_t* col,
                                    const int32_t* edge_ids, const float* invdeg, int transpose,
@@ -881,6 +886,7 @@ extern "C" void qot_debug_stamps(unsigned long long* host8, int reset) {
     if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(qot::g_stamps), z, sizeof(z)); }
     else (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(qot::g_stamps), 8 * sizeof(unsigned long long));
 }
+#endif
 
 // Wp layout (built by the caller, see functional.nnconv_perm_index): with GT = (K+2)*64/8 groups
 // of 4 k-steps, for column half nh, group g, lane l, r in 0..3:
@@ -896,14 +902,17 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
     if (H != 64) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
     if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
+#ifdef QOT_DIAG
     static int use_ws = -1;
     if (use_ws < 0) { const char* e = getenv("QOT_NNCONV_WS"); use_ws = (e && e[0] == '1') ? 1 : 0; }
     if (use_ws && D <= 4 && !g_variant)
         return qot_nnconv_fused_ws(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, transpose, w_perm, bias,
                                    out, N, H, D, act, act_slope, act_p, act_seed, act_step, stream);
+#endif
     int grid = grid_for(N, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     const ActParams ap = make_act(act, act_slope, act_p, act_seed, act_step);
+#ifdef QOT_DIAG
     if (g_variant && D == 4 && !transpose) {
         if (g_variant == 3)
             nnconv_mfma64_kernel<4, false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
@@ -917,6 +926,7 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
         QOT_LAUNCH_CHECK();
         return QOT_OK;
     }
+#endif
     QOT_DISPATCH_D(D, {
         if (transpose)
             nnconv_mfma64_kernel<kD, true><<<grid, 256, 0, (hipStream_t)stream>>>(

@@ -455,8 +455,15 @@ class NNConvFn(torch.autograd.Function):
         x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, y, act_step = ctx.saved_tensors
         graph = ctx.graph
         g = _f32c(g)
-        if ctx.side is not None and "gbias" in ctx.side:
-            gbias = ctx.side.pop("gbias")          # consumer already went back through the activation
+        if ctx.side is not None:
+            # folded mode (decided at forward time): the consumer's backward (HeadFn) has gone back through this
+            # layer's activation and left the bias gradient here; ``g`` is wrt the PRE-activation output.  The entry
+            # is rewritten by every HeadFn.backward, so a second backward over a retained graph stays correct.
+            if "gbias" not in ctx.side:
+                raise RuntimeError("NNConv output was folded into the fused read-out, but the read-out's backward "
+                                   "has not run: the conv output must feed only the read-out head "
+                                   "(set model._qot_fold_head = False for other graphs)")
+            gbias = ctx.side["gbias"]
         elif ctx.act is not None:
             g, gbias = act_backward_colsum(g, y, ctx.act + (act_step,))
         else:
@@ -708,6 +715,8 @@ class BnFn(torch.autograd.Function):
         elif training:
             if N == 0:
                 raise ValueError("BatchNorm in training mode needs at least one row")
+            if N == 1:      # as torch.nn.BatchNorm1d in training mode
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {C}]")
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
             part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)

@@ -54,6 +54,31 @@ class TopologicalGNN(nn.Module):
         seed = (self._qot_seed + 0x9E3779B97F4A7C15 * (site + 1)) & 0xFFFFFFFFFFFFFFFF
         return (0.01, p, seed, step if p > 0.0 else None)
 
+    def _check_node_ids(self, data, maps):
+        """``nn.Embedding`` raises ``IndexError`` for an id outside ``[0, num_nodes)`` (models.py:12,52; the
+        reference marks ``num_nodes`` "adjust according to your data").  Table mode: ids are ``arange(n)`` per
+        graph (verified when the hint was set), so ``n <= V`` is a host comparison.  Per-node mode: one device
+        read per batch object, remembered in its cache (skipped while a stream capture is running: the batch
+        object has then been through an eager step already)."""
+        V = self.node_embeddings.num_embeddings
+        if maps is not None:
+            if int(maps[3][1]) > V:
+                raise IndexError("index out of range in self")
+            return
+        ids = data.node_ids
+        c = getattr(data, "_qot_cache", None)
+        tag = (ids.data_ptr(), ids._version, tuple(ids.shape), V)
+        if isinstance(c, dict) and c.get("ids_ok") == tag:
+            return
+        if ids.numel():
+            if torch.cuda.is_current_stream_capturing():
+                return
+            lo, hi = torch.aminmax(ids)
+            if int(lo) < 0 or int(hi) >= V:
+                raise IndexError("index out of range in self")
+        if isinstance(c, dict):
+            c["ids_ok"] = tag
+
     def forward(self, data):
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
         maps = None
@@ -61,6 +86,7 @@ class TopologicalGNN(nn.Module):
             n = data.node_ids.shape[0]
             graph = graph_index_for(data, n)
             maps = table_maps_for(data, graph)
+            self._check_node_ids(data, maps)
             if maps is None:
                 x = QF.EmbedFn.apply(self.node_embeddings.weight, cached_i32(data, "node_ids"))
         else:

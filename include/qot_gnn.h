@@ -186,15 +186,6 @@ int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const flo
                      const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
                      int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
                      qot_stream_t stream);
-/* Weight-stationary form of qot_nnconv_fused (same arguments, same result up to fp32 summation
- * order; H == 64, D <= 4): Wcat stays in registers, source rows reach LDS by DMA and every lane
- * forms its MFMA operand on the fly (csrc/nnconv_ws.hip). */
-int qot_nnconv_fused_ws(const float* x, int ld_x, const float* edge_attr, const float* w1,
-                        const float* b1, const int32_t* rowptr, const int32_t* col,
-                        const int32_t* edge_ids, const float* invdeg, int transpose,
-                        const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
-                        int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
-                        qot_stream_t stream);
 /* C[KT,64] = A[N,KT]^T @ G[N,64] (fp32 MFMA, operands streamed from HBM in fragment order,
  * deterministic slab reduction).  Weight-gradient GEMM of NNConv (gWcat = A^T g) -- the shape
  * library GEMMs run at 13-28 TFLOP/s.  KT multiple of 128, <= 1280.  workspace:
