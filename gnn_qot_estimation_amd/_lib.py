@@ -25,7 +25,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 3          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 4          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -51,6 +51,8 @@ SIGNATURES = {
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
                                 _int, _f, _f, _u64, _p, _p]),
+    "qot_nnconv_dw_workspace_floats": (_sz, [_i64, _int, _int]),
+    "qot_nnconv_dw": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_gemm_tn_workspace_floats": (_sz, [_int]),
     "qot_gemm_tn": (_int, [_p, _int, _p, _int, _i64, _int, _p, _p, _p]),
     "qot_nnconv_adjoint_dw_workspace_floats": (_sz, [_int]),

@@ -1,0 +1,744 @@
+// Width-generic fused NNConv (H in {16, 32, 128, 256}; H = 64 has its own tuned kernels in nnconv_mfma.hip).
+//
+// Reference site: topological_training/models.py:20-30,57 (edge MLP + [PyG-ext] NNConv(aggr="mean")); algebra in
+// nnconv.hip: out_i = bias + A_i @ Wcat with A_i = [inv_i sum_e h_e[k] x_j (k < K) | inv_i sum_e x_j | x_i].
+// No width materialises A ([N, (K+2)H]: 5.2 GB per layer at BASELINE configs[3]) in HBM any more:
+//
+//   nnconv_gen_kernel      forward, and (TRANSPOSE) the adjoint grad_x = U @ WcatT over the CSC.  A 32-row operand
+//                          tile lives in LDS only, one PASS per 64 input channels (H >= 128: 2 or 4 passes; the
+//                          [32 x H] accumulator tile stays in registers across the passes), fp32 MFMA 32x32x2.
+//                          H >= 128: a wave owns H/128 column blocks and the whole inner dimension (no cross-wave
+//                          reduction); H <= 32: the four waves split the inner dimension and meet through LDS.
+//   nnconv_dw_gen_kernel   weight gradient dWcat = A^T g.  The [(K+2)H, H] result does not fit any register file, so
+//                          a workgroup owns a SLICE of it (all K+2 blocks x 16 input channels x <= 128 output
+//                          columns, 80 accumulator registers per lane) and a strided share of the 32-node tiles; it
+//                          gathers only its 16 channels of the operand.  Slabs are summed in a fixed order by
+//                          nnconv_dw_final_kernel straight into the parameters' own layouts.
+//   nnconv_gradh_gen_kernel  grad of the edge MLP's first layer: per tile GA = g_tile @ Wk^T for 32 input channels at
+//                          a time on the matrix cores, per-edge dots against the source rows; with more than one
+//                          channel pass the per-edge partial dots wait in LDS (edges of a tile are one CSR range).
+// All sums have a fixed order: bitwise reproducible, independent of where a graph sits in the batch.
+#include "common.hpp"
+#include "mfma_tile.hpp"
+
+namespace qot {
+
+template <int CPL>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[CPL]) {
+    if constexpr (CPL == 8) {
+        const float4 a = ld4(p), b = ld4(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (CPL == 4) {
+        const float4 a = ld4(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    } else {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        v[0] = a.x; v[1] = a.y;
+    }
+}
+
+// Gather of one destination's operand blocks by its 8-lane group, CPL channels per lane starting at channel
+// `cbase` of the rows (x + row*ldx + cbase).  Lane `sub` prefetches in-edge `sub` of a batch of eight (source, edge
+// id, features) and evaluates that edge's h = relu(W1 ea + b1) once; broadcasts on the DPP path; four source rows in
+// flight.  acc[kk] (kk < K): sum_e h_e[kk] x_j, acc[K]: sum_e x_j, scaled by the destination's 1/deg (forward) or
+// with 1/deg of the gathered end folded into h (TRANSPOSE); root = the node's own row.  i >= N gives zeros.
+template <int D, int CPL, bool TRANSPOSE>
+__device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx, int cbase, const float* __restrict__ ea,
+                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                           const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, int64_t i,
+                                           int64_t N, int lo, int hi_, float (&acc)[2 * D + 1][CPL], float (&root)[CPL]) {
+    constexpr int K = 2 * D;
+    const int sub = threadIdx.x & 7;
+#pragma unroll
+    for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[kk][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) root[c] = 0.f;
+    int beg = 0, end = 0;
+    float srow = 0.f;
+    if (i < N) {
+        beg = rowptr[i]; end = rowptr[i + 1];
+        if (beg < lo) beg = lo;
+        if (end > hi_) end = hi_;
+        if (!TRANSPOSE) srow = invdeg[i];
+        ldv<CPL>(x + i * ldx + cbase, root);
+    }
+    const bool upper = (sub & 4) != 0;
+    for (int base = beg; base < end; base += 8) {
+        const int p = base + sub;
+        int myj = 0;
+        float myh[K], mysc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
+        if (p < end) {
+            myj = col[p];
+            const int64_t e = eidx[p];
+            float ee[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+            mysc = TRANSPOSE ? invdeg[myj] : 1.0f;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                float h = b1[kk];
+#pragma unroll
+                for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
+                myh[kk] = fmaxf(h, 0.f) * mysc;
+            }
+        }
+        const int cnt = (end - base < 8) ? end - base : 8;
+#define QOT_GEN_EDGE4(U0)                                                                                \
+        {                                                                                                \
+            float xv[4][CPL];                                                                            \
+            float sc[4];                                                                                 \
+            int jj[4];                                                                                   \
+            jj[0] = group8_bcast<U0 + 0>(myj, upper); jj[1] = group8_bcast<U0 + 1>(myj, upper);          \
+            jj[2] = group8_bcast<U0 + 2>(myj, upper); jj[3] = group8_bcast<U0 + 3>(myj, upper);          \
+            sc[0] = group8_bcast<U0 + 0>(mysc, upper); sc[1] = group8_bcast<U0 + 1>(mysc, upper);        \
+            sc[2] = group8_bcast<U0 + 2>(mysc, upper); sc[3] = group8_bcast<U0 + 3>(mysc, upper);        \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const bool live = U0 + u < cnt;                                                          \
+                ldv<CPL>(x + (live ? (int64_t)jj[u] : 0) * ldx + cbase, xv[u]);                          \
+                if (!live) sc[u] = 0.f;                                                                  \
+            }                                                                                            \
+            _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                           \
+                float h[4];                                                                              \
+                h[0] = group8_bcast<U0 + 0>(myh[kk], upper); h[1] = group8_bcast<U0 + 1>(myh[kk], upper);  \
+                h[2] = group8_bcast<U0 + 2>(myh[kk], upper); h[3] = group8_bcast<U0 + 3>(myh[kk], upper);  \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+                    const float hv = (U0 + u < cnt) ? h[u] : 0.f;                                        \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(hv, xv[u][c], acc[kk][c]); \
+                }                                                                                        \
+            }                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
+                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
+        }
+        QOT_GEN_EDGE4(0)
+        if (cnt > 4) QOT_GEN_EDGE4(4)
+#undef QOT_GEN_EDGE4
+    }
+    if (!TRANSPOSE) {
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[kk][c] *= srow;
+    }
+}
+
+template <int H>
+struct GenW {
+    static constexpr int CW = H < 64 ? H : 64;          // input channels per pass
+    static constexpr int NP = H / CW;                   // passes
+    static constexpr int CPL = CW / 8;                  // channels per lane in the gather (8 lanes per destination)
+    static constexpr int NCB = (H + 31) / 32;           // 32-column blocks of the output (H = 16: half a block)
+    static constexpr int CBW = NCB >= 4 ? NCB / 4 : 1;  // column blocks per wave
+    static constexpr int KS = NCB >= 4 ? 1 : 4 / NCB;   // ways the inner dimension is split over waves
+    static constexpr bool ROOT_LDS = H < 64;            // root block kept in the LDS tile (small tiles only)
+};
+
+// channels [CPL*sub, CPL*sub + CPL) of block kk of one tile row -> fragment-grouped LDS tile (local k = kk*CW + ch)
+template <int CW, int CPL>
+__device__ __forceinline__ void frag_store(float* __restrict__ At, int kk, int sub, int il, const float (&v)[CPL]) {
+    float4* At4 = reinterpret_cast<float4*>(At);
+    if constexpr (CPL == 8) {
+        const int g = kk * (CW / 8) + sub;
+        At4[at4_slot(g, 0, il)] = make_float4(v[0], v[2], v[4], v[6]);
+        At4[at4_slot(g, 1, il)] = make_float4(v[1], v[3], v[5], v[7]);
+    } else if constexpr (CPL == 4) {                   // half a group: components 2*(sub&1), 2*(sub&1)+1
+        const int g = kk * (CW / 8) + (sub >> 1);
+        float2* s0 = reinterpret_cast<float2*>(&At4[at4_slot(g, 0, il)]) + (sub & 1);
+        float2* s1 = reinterpret_cast<float2*>(&At4[at4_slot(g, 1, il)]) + (sub & 1);
+        *s0 = make_float2(v[0], v[2]);
+        *s1 = make_float2(v[1], v[3]);
+    } else {                                           // a quarter of a group: component sub & 3
+        const int g = kk * (CW / 8) + (sub >> 2);
+        At[at4_slot(g, 0, il) * 4 + (sub & 3)] = v[0];
+        At[at4_slot(g, 1, il) * 4 + (sub & 3)] = v[1];
+    }
+}
+
+// Wp layout (functional.nnconv_gen_perm_index): for pass p, column block cb, group g of 8 local k (all K+2 blocks
+// of the pass: local k = kk*CW + channel - p*CW), lane l, r:
+//   Wp[(((p*NCB + cb)*GALL + g)*64 + l)*4 + r] = Wcat[kk*H + p*CW + c][cb*32 + (l & 31)],  8g + 2r + (l>>5) = kk*CW + c
+// (zero where the column is >= H).
+template <int H, int D, bool TRANSPOSE>
+__global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
+    const float* __restrict__ b1, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, const float* __restrict__ Wp,
+    const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act) {
+    using G = GenW<H>;
+    constexpr int K = 2 * D;
+    constexpr int CW = G::CW, NP = G::NP, CPL = G::CPL, NCB = G::NCB, CBW = G::CBW, KS = G::KS;
+    constexpr bool ROOT_LDS = G::ROOT_LDS;
+    constexpr int NBLK = ROOT_LDS ? K + 2 : K + 1;        // blocks resident in LDS
+    constexpr int GMAIN = NBLK * CW / 8;                  // groups in LDS
+    constexpr int GROOT = ROOT_LDS ? 0 : CW / 8;          // root groups multiplied after the main part
+    constexpr int GALL = (K + 2) * CW / 8;                // groups per (pass, column block) in Wp
+    static_assert(GMAIN % KS == 0 && GROOT % KS == 0, "inner split");
+    constexpr int GS = GMAIN / KS, GRS = GROOT / KS;
+    constexpr int CH = (GS % 4 == 0) ? 4 : ((GS % 2 == 0) ? 2 : 1);
+    constexpr int NCH = GS / CH;
+    constexpr int TILE_FLOATS = GMAIN * 8 * 32;
+    constexpr int RED_FLOATS = (KS > 1) ? 4 * 16 * 64 : 0;
+    __shared__ __attribute__((aligned(16))) float At[TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS];
+    const float4* At4 = reinterpret_cast<const float4*>(At);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int cb0 = (KS == 1) ? wave * CBW : wave % NCB;
+    const int ks = (KS == 1) ? 0 : wave / NCB;
+    const int64_t ntiles = (N + 31) / 32;
+
+#pragma unroll 1
+    for (int64_t it = 0;; ++it) {
+        const int64_t tile = xcd_tile(it, ntiles);
+        if (tile < 0) break;
+        const int64_t tile0 = tile * 32;
+        const int64_t i = tile0 + il;
+        f32x16 c[CBW];
+#pragma unroll
+        for (int q = 0; q < CBW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[q][r] = 0.f;
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p) {
+            float root[CPL];
+            {
+                float acc[K + 1][CPL];
+                gen_gather<D, CPL, TRANSPOSE>(x, ldx, p * CW + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N,
+                                              0, 0x7fffffff, acc, root);
+#pragma unroll
+                for (int kk = 0; kk <= K; ++kk) frag_store<CW, CPL>(At, kk, sub, il, acc[kk]);
+                if (ROOT_LDS) frag_store<CW, CPL>(At, K + 1, sub, il, root);
+            }
+            __syncthreads();
+            // ---- main part: this wave's groups [ks*GS, (ks+1)*GS) against its column blocks
+            const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)(p * NCB + cb0) * GALL + ks * GS) * 64 + lane;
+            float4 bc[CBW][CH], bn[CBW][CH];
+#pragma unroll
+            for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + u) * 64];
+            int ch = 0;
+#pragma unroll 1
+            for (; ch + 1 < NCH; ch += 2) {
+#pragma unroll
+                for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) bn[q][u] = wp[((int64_t)q * GALL + (ch + 1) * CH + u) * 64];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float4 a = At4[at4_slot(ks * GS + ch * CH + u, hi, r31)];
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q) {
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[q][u].x, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bc[q][u].y, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bc[q][u].z, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[q][u].w, c[q], 0, 0, 0);
+                    }
+                }
+                if (ch + 2 < NCH) {
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + (ch + 2) * CH + u) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float4 a = At4[at4_slot(ks * GS + (ch + 1) * CH + u, hi, r31)];
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q) {
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bn[q][u].x, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bn[q][u].y, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bn[q][u].z, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bn[q][u].w, c[q], 0, 0, 0);
+                    }
+                }
+            }
+            if (NCH & 1) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float4 a = At4[at4_slot(ks * GS + (NCH - 1) * CH + u, hi, r31)];
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q) {
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[q][u].x, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bc[q][u].y, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bc[q][u].z, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[q][u].w, c[q], 0, 0, 0);
+                    }
+                }
+            }
+            if (!ROOT_LDS) {
+                // ---- root block (the node's own row) takes block 0's slots once everyone is done with the tile
+                float4 rb[CBW][GRS > 0 ? GRS : 1];
+                const float4* wr = reinterpret_cast<const float4*>(Wp) + ((int64_t)(p * NCB + cb0) * GALL + GMAIN + ks * GRS) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < CBW; ++q)
+#pragma unroll
+                    for (int u = 0; u < GRS; ++u) rb[q][u] = wr[((int64_t)q * GALL + u) * 64];
+                lds_barrier();
+                frag_store<CW, CPL>(At, 0, sub, il, root);
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < GRS; ++u) {
+                    const float4 a = At4[at4_slot(ks * GRS + u, hi, r31)];
+#pragma unroll
+                    for (int q = 0; q < CBW; ++q) {
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, rb[q][u].x, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, rb[q][u].y, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, rb[q][u].z, c[q], 0, 0, 0);
+                        c[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, rb[q][u].w, c[q], 0, 0, 0);
+                    }
+                }
+            }
+            lds_barrier();                 // the tile is rewritten by the next pass / tile (or becomes `red`)
+        }
+        // ---- epilogue: bias, leaky_relu + dropout, 128-B row segments
+        if constexpr (KS == 1) {
+#pragma unroll
+            for (int q = 0; q < CBW; ++q) {
+                const int colg = (cb0 + q) * 32 + r31;
+                const float bz = bias ? bias[colg] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int64_t io = tile0 + row;
+                    if (io < N) out[io * H + colg] = act_apply1(c[q][r] + bz, act, (uint64_t)(io * H + colg));
+                }
+            }
+        } else {
+            float* red = At;               // [wave][16][64]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = c[0][r];
+            lds_barrier();
+            constexpr int RPW = 16 / KS;   // accumulator registers finished by each wave of a column block
+            const int colg = cb0 * 32 + r31;
+            const float bz = (bias && colg < H) ? bias[colg] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int r = ks * RPW + rr;
+                float v = bz;
+#pragma unroll
+                for (int k2 = 0; k2 < KS; ++k2) v += red[((cb0 + NCB * k2) * 16 + r) * 64 + lane];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int64_t io = tile0 + row;
+                if (io < N && colg < H) out[io * H + colg] = act_apply1(v, act, (uint64_t)(io * H + colg));
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+template <int H>
+struct DwW {
+    static constexpr int AC = 16;                                   // input channels of a slice
+    static constexpr int NAC = H / AC;
+    static constexpr int OC = H >= 128 ? 128 : (H < 32 ? 32 : H);   // output columns of a slice (H = 16: padded)
+    static constexpr int NOC = (H + OC - 1) / OC;
+    static constexpr int OCB = OC / 32;
+    static constexpr int NSLICE = NAC * NOC;
+};
+
+template <int H, int D>
+__global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg, const float* __restrict__ ea,
+    const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
+    float* __restrict__ slabs, int64_t N, int nsplit) {
+    using W = DwW<H>;
+    constexpr int K = 2 * D;
+    constexpr int AC = W::AC, NAC = W::NAC, OC = W::OC, OCB = W::OCB, NSLICE = W::NSLICE;
+    constexpr int ROWS = (K + 2) * AC;              // rows of the slice of dWcat: (kk, a - a0)
+    constexpr int RB = ROWS / 32;
+    static_assert(ROWS % 32 == 0, "K + 2 even");
+    constexpr int NT = RB * OCB;                    // 32x32 accumulator tiles of the slice
+    constexpr int TPW = (NT + 3) / 4;               // per wave (tile t belongs to wave t % 4)
+    __shared__ __attribute__((aligned(16))) float Atile[32 * ROWS];
+    __shared__ __attribute__((aligned(16))) float Gt[32 * OC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int slice = blockIdx.x % NSLICE, split = blockIdx.x / NSLICE;
+    const int a0 = (slice % NAC) * AC, o0 = (slice / NAC) * OC;
+    const int64_t ntiles = (N + 31) / 32;
+
+    f32x16 dw[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[t][r] = 0.f;
+    // tile tt = wave + 4t has column block tt % OCB = wave % OCB for every t (OCB divides 4): one B operand per step
+    static_assert(4 % OCB == 0, "column block per wave");
+    int aoff[TPW];
+    const int boff = hi * OC + (wave % OCB) * 32 + r31;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tt = wave + 4 * t;
+        const int rb = (tt < NT) ? tt / OCB : 0;
+        aoff[t] = hi * ROWS + rb * 32 + r31;
+    }
+#pragma unroll 1
+    for (int64_t tile = split; tile < ntiles; tile += nsplit) {
+        const int64_t tile0 = tile * 32;
+        const int64_t i = tile0 + il;
+        // this thread's piece of the g tile (row il, columns o0 + (OC/8)*sub ...) goes straight to LDS: the previous
+        // tile's readers are behind the barrier that ended its iteration
+        {
+            const bool ok = i < N;
+#pragma unroll
+            for (int q = 0; q < OC / 8; q += 4) {
+                const int cc = o0 + (OC / 8) * sub + q;
+                const float4 v = (ok && cc < H) ? ld4(g + i * ldg + cc) : f4zero();
+                *reinterpret_cast<float4*>(&Gt[il * OC + (OC / 8) * sub + q]) = v;
+            }
+        }
+        float acc[K + 1][2], root[2];
+        gen_gather<D, 2, false>(x, ldx, a0 + 2 * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, 0, 0x7fffffff, acc, root);
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk)
+            *reinterpret_cast<float2*>(&Atile[il * ROWS + kk * AC + 2 * sub]) = make_float2(acc[kk][0], acc[kk][1]);
+        *reinterpret_cast<float2*>(&Atile[il * ROWS + (K + 1) * AC + 2 * sub]) = make_float2(root[0], root[1]);
+        __syncthreads();
+        // dW[(kk,a), o] += sum over the tile's nodes: A operand = the tile read transposed (node = k index)
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            float av[TPW];
+            const float bv = Gt[boff + 2 * s * OC];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) av[t] = Atile[aoff[t] + 2 * s * ROWS];
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (wave + 4 * t < NT) dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, dw[t], 0, 0, 0);
+        }
+        lds_barrier();
+    }
+    // slab[blockIdx][row (kk, a - a0)][o - o0]
+    float* slab = slabs + (int64_t)blockIdx.x * ROWS * OC;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tt = wave + 4 * t;
+        if (tt < NT) {
+            const int rb = tt / OCB, cb = tt % OCB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                slab[(rb * 32 + row) * OC + cb * 32 + r31] = dw[t][r];
+            }
+        }
+    }
+}
+
+// sum over the node splits (fixed order), written straight into the parameters' layouts:
+//   dst = [ g(nn.2.weight)[a*H+o, k] (H*H*K) | g(nn.2.bias)[a*H+o] (H*H) | g(lin.weight)[o, a] (H*H) ]
+template <int H>
+__global__ void nnconv_dw_final_kernel(const float* __restrict__ slabs, int nsplit, int K, float* __restrict__ dst) {
+    using W = DwW<H>;
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t hh = (int64_t)H * H;
+    if (e >= hh * (K + 2)) return;
+    int kk, a, o;
+    if (e < hh * K) { kk = (int)(e % K); const int64_t ao = e / K; a = (int)(ao / H); o = (int)(ao % H); }
+    else if (e < hh * (K + 1)) { kk = K; const int64_t ao = e - hh * K; a = (int)(ao / H); o = (int)(ao % H); }
+    else { kk = K + 1; const int64_t oa = e - hh * (K + 1); o = (int)(oa / H); a = (int)(oa % H); }
+    const int slice = (a / W::AC) + W::NAC * (o / W::OC);
+    const int rows = (K + 2) * W::AC;
+    const int64_t off = ((int64_t)slice * rows + kk * W::AC + (a % W::AC)) * W::OC + (o % W::OC);
+    const int64_t stride = (int64_t)W::NSLICE * rows * W::OC;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slabs[sp * stride + off];
+    dst[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- grad of nn.0.*
+// Bp layout (functional.nnconv_gen_gradh_perm_index): pass p (32 input channels, or H when H < 32), 32-column block
+// nb of GA_p (column n = k*CWG + al), group gq of 8 output channels o, lane l, r:
+//   Bp[(((p*NBG + nb)*GH + gq)*64 + l)*4 + r] = W2[(p*CWG + al)*H + o, k],  o = 8 gq + 2r + (l>>5),  n = nb*32 + (l&31)
+constexpr int kEdgeCap = 256;      // per-edge partial dots kept in LDS between channel passes (one segment)
+
+template <int H, int D>
+__global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
+    const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, const float* __restrict__ ea,
+    const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
+    const float* __restrict__ Bp, float* __restrict__ partials, int64_t N) {
+    constexpr int K = 2 * D;
+    static_assert(K <= 8, "one k per lane of the 8-lane group");
+    constexpr int CWG = H < 32 ? H : 32;
+    constexpr int NPG = H / CWG;
+    constexpr int CPL = CWG / 8;                  // 4 (or 2 at H = 16)
+    constexpr int NBG = K * CWG / 32;             // 32-column blocks of GA_p
+    constexpr int GH = H / 8;                     // groups of 8 output channels
+    constexpr int LDGA = K * CWG + 4;
+    __shared__ __attribute__((aligned(16))) float Gt[GH * 2 * 32 * 4];
+    __shared__ __attribute__((aligned(16))) float GAt[32 * LDGA > 2 * (D + 1) * 256 ? 32 * LDGA : 2 * (D + 1) * 256];
+    __shared__ float pe[(NPG > 1) ? kEdgeCap * 8 : 8];
+    float4* Gt4 = reinterpret_cast<float4*>(Gt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r31 = lane & 31, hi = lane >> 5;
+    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int64_t ntiles = (N + 31) / 32;
+
+    float wrow[D], brow, aw[D], ab = 0.f;         // lane-owned row k = sub of the first edge-MLP layer
+    brow = (sub < K) ? b1[sub] : 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { wrow[d] = (sub < K) ? w1[sub * D + d] : 0.f; aw[d] = 0.f; }
+
+#pragma unroll 1
+    for (int64_t it = 0;; ++it) {
+        const int64_t tile = xcd_tile(it, ntiles);
+        if (tile < 0) break;
+        const int64_t tile0 = tile * 32;
+        const int64_t i = tile0 + il;
+        const int64_t tend = (tile0 + 32 < N) ? tile0 + 32 : N;
+        const int e_t0 = rowptr[tile0], e_t1 = rowptr[tend];
+        if (e_t0 == e_t1) continue;               // no in-edges in this tile (uniform)
+        // g tile -> LDS, fragment-grouped over the output channels o
+        for (int gq = sub; gq < GH; gq += 8) {
+            float4 g0 = f4zero(), g1 = f4zero();
+            if (i < N) { g0 = ld4(g + i * ldg + 8 * gq); g1 = ld4(g + i * ldg + 8 * gq + 4); }
+            Gt4[at4_slot(gq, 0, il)] = make_float4(g0.x, g0.z, g1.x, g1.z);
+            Gt4[at4_slot(gq, 1, il)] = make_float4(g0.y, g0.w, g1.y, g1.w);
+        }
+        const float sc = (i < N) ? invdeg[i] : 0.f;
+        int beg = 0, end = 0;
+        if (i < N) { beg = rowptr[i]; end = rowptr[i + 1]; }
+#pragma unroll 1
+        for (int seg0 = e_t0; seg0 < e_t1; seg0 += kEdgeCap) {
+            const int seg1 = seg0 + kEdgeCap;
+            const int sb = beg > seg0 ? beg : seg0, se = end < seg1 ? end : seg1;   // this destination's edges in the segment
+#pragma unroll 1
+            for (int p = 0; p < NPG; ++p) {
+                lds_barrier();            // Gt / pe written; GAt free
+                // GA_p tile on the matrix cores
+                for (int nb = wave; nb < NBG; nb += 4) {
+                    const float4* bp = reinterpret_cast<const float4*>(Bp) + ((int64_t)(p * NBG + nb) * GH) * 64 + lane;
+                    f32x16 c;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll 4
+                    for (int gq = 0; gq < GH; ++gq) c = mfma_group(Gt4, gq, hi, r31, bp[gq * 64], c);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        GAt[row * LDGA + nb * 32 + r31] = c[r];
+                    }
+                }
+                lds_barrier();
+                // per-edge dots over this pass's channels
+                if (sb < se) {
+                    float ga[K][CPL];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) ldv<CPL>(&GAt[il * LDGA + k * CWG + CPL * sub], ga[k]);
+                    const int cbase = p * CWG + CPL * sub;
+                    for (int base = sb; base < se; base += 8) {
+                        const int pp = base + sub;
+                        int myj = 0;
+                        float mye[D];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) mye[d] = 0.f;
+                        if (pp < se) {
+                            myj = col[pp];
+                            if (p == NPG - 1) {
+                                const int64_t e = eidx[pp];
+#pragma unroll
+                                for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+                            }
+                        }
+                        const int cnt = (se - base < 8) ? se - base : 8;
+                        for (int u0 = 0; u0 < cnt; u0 += 4) {
+                            float xr[4][CPL];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int64_t j = __shfl(myj, u0 + u, 8);
+                                ldv<CPL>(x + (u0 + u < cnt ? j : 0) * ldx + cbase, xr[u]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool live = u0 + u < cnt;
+                                float pd[8];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    float a = 0.f;
+                                    if (k < K) {
+#pragma unroll
+                                        for (int t = 0; t < CPL; ++t) a = fmaf(ga[k < K ? k : 0][t], xr[u][t], a);
+                                    }
+                                    pd[k] = a;
+                                }
+                                // transpose-reduce 8 values over the 8 lanes: lane s ends with the total of value s
+                                float t4[4];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    const float keep = (sub & 4) ? pd[m + 4] : pd[m];
+                                    const float send = (sub & 4) ? pd[m] : pd[m + 4];
+                                    t4[m] = keep + dpp_move<0x141>(send);
+                                }
+                                float t2[2];
+#pragma unroll
+                                for (int m = 0; m < 2; ++m) {
+                                    const float keep = (sub & 2) ? t4[m + 2] : t4[m];
+                                    const float send = (sub & 2) ? t4[m] : t4[m + 2];
+                                    t2[m] = keep + dpp_move<0x4E>(send);
+                                }
+                                const float keep = (sub & 1) ? t2[1] : t2[0];
+                                const float send = (sub & 1) ? t2[0] : t2[1];
+                                float tot = keep + dpp_move<0xB1>(send);          // k = sub
+                                const int slot = (base + u0 + u - seg0) * 8 + sub;
+                                if (NPG > 1 && live) {
+                                    if (p > 0) tot += pe[slot];
+                                    if (p < NPG - 1) pe[slot] = tot;
+                                }
+                                if (p == NPG - 1) {
+                                    float ee[D];
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, 8);
+                                    float pre = brow;
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) pre = fmaf(wrow[d], ee[d], pre);
+                                    const float gh = (live && pre > 0.f && sub < K) ? tot * sc : 0.f;
+                                    ab += gh;
+#pragma unroll
+                                    for (int d = 0; d < D; ++d) aw[d] = fmaf(gh, ee[d], aw[d]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            lds_barrier();                // pe / GAt are rewritten by the next segment / tile
+        }
+    }
+    // block partial: sum the 32 lane groups (fixed order) -> partials[blk][K*(D+1)]
+    lds_barrier();
+    float* red = GAt;
+#pragma unroll
+    for (int d = 0; d < D; ++d) red[(d * 32 + il) * 8 + sub] = aw[d];
+    red[(D * 32 + il) * 8 + sub] = ab;
+    lds_barrier();
+    if (threadIdx.x < (D + 1) * 8) {
+        const int s8 = threadIdx.x & 7, d = threadIdx.x >> 3;
+        float sum = 0.f;
+        for (int g32 = 0; g32 < 32; ++g32) sum += red[(d * 32 + g32) * 8 + s8];
+        if (s8 < K) partials[(int64_t)blockIdx.x * (K * (D + 1)) + (d < D ? s8 * D + d : K * D + s8)] = sum;
+    }
+}
+
+__global__ void gen_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, int KD,
+                                       float* __restrict__ gw1, float* __restrict__ gb1) {
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per output
+    if (t >= n) return;
+    const float s = wave_sum_partials(partials, nblk, n, t);
+    if ((threadIdx.x & 63) == 0) { if (t < KD) gw1[t] = s; else gb1[t - KD] = s; }
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+#define QOT_DISPATCH_GEN_H(H, ...)                               \
+    switch (H) {                                                 \
+        case 16:  { constexpr int kH = 16;  __VA_ARGS__; } break;  \
+        case 32:  { constexpr int kH = 32;  __VA_ARGS__; } break;  \
+        case 64:  { constexpr int kH = 64;  __VA_ARGS__; } break;  \
+        case 128: { constexpr int kH = 128; __VA_ARGS__; } break;  \
+        case 256: { constexpr int kH = 256; __VA_ARGS__; } break;  \
+        default: return QOT_ERR_UNSUPPORTED;                     \
+    }
+#define QOT_DISPATCH_D4(D, ...)                                  \
+    switch (D) {                                                 \
+        case 1: { constexpr int kD = 1; __VA_ARGS__; } break;    \
+        case 2: { constexpr int kD = 2; __VA_ARGS__; } break;    \
+        case 3: { constexpr int kD = 3; __VA_ARGS__; } break;    \
+        case 4: { constexpr int kD = 4; __VA_ARGS__; } break;    \
+        default: return QOT_ERR_UNSUPPORTED;                     \
+    }
+
+// Width-generic form of qot_nnconv_fused (same arguments; w_perm in the per-pass layout documented above).
+int qot_nnconv_gen_launch(const float* x, int ld_x, const float* edge_attr, const float* w1, const float* b1,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* edge_ids, const float* invdeg,
+                          int transpose, const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                          const ActParams& ap, hipStream_t stream) {
+    int grid = grid_for(N, 32);
+    if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
+        if (transpose)
+            nnconv_gen_kernel<kH, kD, true><<<grid, 256, 0, stream>>>(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids,
+                                                                       invdeg, w_perm, bias, out, N, ap);
+        else
+            nnconv_gen_kernel<kH, kD, false><<<grid, 256, 0, stream>>>(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids,
+                                                                        invdeg, w_perm, bias, out, N, ap);
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+static int dw_splits(int64_t N, int nslice) {
+    const int64_t ntiles = (N + 31) / 32;
+    int64_t s = (4 * (int64_t)num_cus() + nslice - 1) / nslice;      // ~4 workgroups per CU in all
+    if (s > ntiles) s = ntiles;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static int dw_nslice(int H) {
+    switch (H) {
+        case 16: return DwW<16>::NSLICE;
+        case 32: return DwW<32>::NSLICE;
+        case 64: return DwW<64>::NSLICE;
+        case 128: return DwW<128>::NSLICE;
+        case 256: return DwW<256>::NSLICE;
+    }
+    return 0;
+}
+static int dw_oc(int H) { return H >= 128 ? 128 : (H < 32 ? 32 : H); }
+
+extern "C" size_t qot_nnconv_dw_workspace_floats(int64_t N, int H, int D) {
+    const int ns = dw_nslice(H);
+    if (!ns || N <= 0) return 16;
+    return (size_t)dw_splits(N, ns) * ns * (size_t)((2 * D + 2) * 16) * dw_oc(H);
+}
+
+// Weight gradient of NNConv for any supported width: grad_params = [g(nn.2.weight) | g(nn.2.bias) | g(lin.weight)]
+// ((2D+2)*H*H floats, the parameters' own layouts) from x, grad_out and the CSR (by destination).
+extern "C" int qot_nnconv_dw(const float* x, int ld_x, const float* grad_out, int ld_g, const float* edge_attr,
+                             const float* w1, const float* b1, const int32_t* rowptr, const int32_t* col,
+                             const int32_t* eid, const float* invdeg, float* grad_params, float* workspace, int64_t N,
+                             int H, int D, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || !rowptr) return QOT_ERR_BADARG;
+    if (!x || !grad_out || !w1 || !b1 || !invdeg || !grad_params || !workspace || (ld_x & 3) || (ld_g & 3))
+        return QOT_ERR_BADARG;
+    const int ns = dw_nslice(H);
+    if (!ns) return QOT_ERR_UNSUPPORTED;
+    const int nsplit = dw_splits(N, ns);
+    QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
+        nnconv_dw_gen_kernel<kH, kD><<<nsplit * ns, 256, 0, stream>>>(x, ld_x, grad_out, ld_g, edge_attr, w1, b1, rowptr,
+                                                                      col, eid, invdeg, workspace, N, nsplit);
+        QOT_LAUNCH_CHECK();
+        const int64_t elems = (int64_t)(2 * kD + 2) * kH * kH;
+        nnconv_dw_final_kernel<kH><<<grid_for(elems, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+int qot_nnconv_gradh_gen_launch(const float* grad_out, int ld_g, const float* x, int ld_x, const float* edge_attr,
+                                const float* w1, const float* b1, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* eid, const float* invdeg, const float* b_perm, float* gw1, float* gb1,
+                                float* workspace, int64_t N, int H, int D, hipStream_t stream) {
+    int grid = grid_for(N > 0 ? N : 1, 32);
+    if (grid > 2 * num_cus()) grid = 2 * num_cus();
+    const int K = 2 * D;
+    QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
+        nnconv_gradh_gen_kernel<kH, kD><<<grid, 256, 0, stream>>>(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col,
+                                                                  eid, invdeg, b_perm, workspace, N);
+    }));
+    QOT_LAUNCH_CHECK();
+    const int n = K * (D + 1);
+    gen_partial_sum_kernel<<<grid_for(n, 4), 256, 0, stream>>>(workspace, grid, n, K * D, gw1, gb1);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

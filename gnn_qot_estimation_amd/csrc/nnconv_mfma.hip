@@ -24,18 +24,9 @@
 // One workgroup gathers while its CU-mate owns the MFMA pipes.  TRANSPOSE runs the adjoint (grad_x) over the CSC with the mean scale taken at
 // the gathered end.
 #include "common.hpp"
+#include "mfma_tile.hpp"
 
 namespace qot {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// LDS operand tile, "fragment-grouped": k = 8*g + 2*r + hi  ->  float4 slot
-//   At4[(2*g + hi)*32 + (i ^ (g & 7))] component r
-// so the 4 A fragments a lane feeds to 4 consecutive MFMAs are ONE ds_read_b128, and the
-// gather's 8 channels per lane (= one group g) are TWO ds_write_b128 (hi = 0 / 1).  The XOR
-// spreads the 8 lanes of a destination (g & 7 = 0..7) over all 32 banks: both sides
-// conflict-free.
-__device__ __forceinline__ int at4_slot(int g, int hi, int i) { return (2 * g + hi) * 32 + (i ^ (g & 7)); }
 
 // Phase 1.  8 lanes per destination (2 x float4 = 64 channels each), so the 32 destinations of
 // a tile are gathered in ONE pass by the 256 threads.  Lane `sub` of a destination's group
@@ -139,43 +130,6 @@ __device__ __forceinline__ void nnconv_gather_tile(
         At4[at4_slot(g, 0, il)] = make_float4(acc0[kk].x, acc0[kk].z, acc1[kk].x, acc1[kk].z);
         At4[at4_slot(g, 1, il)] = make_float4(acc0[kk].y, acc0[kk].w, acc1[kk].y, acc1[kk].w);
     }
-}
-
-// One 4-MFMA group g: A fragments = one float4 from the LDS tile, B fragments = one float4 of Wp.
-__device__ __forceinline__ f32x16 mfma_group(const float4* __restrict__ At4, int g, int hi, int r31, float4 b,
-                                             f32x16 c) {
-    const float4 a = At4[at4_slot(g, hi, r31)];
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
-    return c;
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits vmcnt(0), i.e. it
-// drains the epilogue's global stores (measured: ~30 % of the tile time went there).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// XCD-aware persistent tile walk.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
-// labels the XCD group -- speed only, never correctness), and each XCD has a private L2.  A graph's
-// rows are gathered by the 3-4 consecutive tiles that hold its destinations, so every XCD group
-// walks its own contiguous eighth of the tiles: the rows a tile gathers are then already in that
-// XCD's L2 from the neighbouring tile.  Returns the tile of iteration `it` (or -1 when done).
-__device__ __forceinline__ int64_t xcd_tile(int64_t it, int64_t ntiles) {
-    const int nx = 8;
-    if ((int)gridDim.x % nx != 0) {                        // small grids: plain strided walk
-        const int64_t t = (int64_t)blockIdx.x + it * gridDim.x;
-        return t < ntiles ? t : -1;
-    }
-    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, per_x = gridDim.x / nx;
-    const int64_t chunk = (ntiles + nx - 1) / nx;
-    const int64_t local = slot + it * per_x;
-    const int64_t t = xcd * chunk + local;
-    return (local < chunk && t < ntiles) ? t : -1;
 }
 
 // diagnostic build only (make DIAG=1, VARIANT 3): per-phase cycle sums, one adder per wave
@@ -861,16 +815,15 @@ __global__ void gradh_partial_sum_kernel(const float* __restrict__ partials, int
 
 using namespace qot;
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+// width-generic kernels (nnconv_gen.hip)
+int qot_nnconv_gen_launch(const float* x, int ld_x, const float* edge_attr, const float* w1, const float* b1,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* edge_ids, const float* invdeg,
+                          int transpose, const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
+                          const ActParams& ap, hipStream_t stream);
+int qot_nnconv_gradh_gen_launch(const float* grad_out, int ld_g, const float* x, int ld_x, const float* edge_attr,
+                                const float* w1, const float* b1, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* eid, const float* invdeg, const float* b_perm, float* gw1, float* gb1,
+                                float* workspace, int64_t N, int H, int D, hipStream_t stream);
 
 #ifdef QOT_DIAG
 extern "C" int qot_nnconv_fused_ws(const float* x, int ld_x, const float* edge_attr, const float* w1,
@@ -899,9 +852,16 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
                                 int act, float act_slope, float act_p, uint64_t act_seed,
                                 const int64_t* act_step, qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
-    if (H != 64) return QOT_ERR_UNSUPPORTED;
+    if (H != 16 && H != 32 && H != 64 && H != 128 && H != 256) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
     if (!x || !w1 || !b1 || !invdeg || !w_perm || !out || (ld_x & 3)) return QOT_ERR_BADARG;
+    if (H != 64 || transpose == 2 || transpose == 3) {
+        // other widths (and, for A/B measurements, H = 64 with transpose = 2 / 3): the per-pass tile kernel
+        if (D > 4) return QOT_ERR_UNSUPPORTED;
+        return qot_nnconv_gen_launch(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, transpose & 1, w_perm,
+                                     bias, out, N, H, D, make_act(act, act_slope, act_p, act_seed, act_step),
+                                     (hipStream_t)stream);
+    }
 #ifdef QOT_DIAG
     static int use_ws = -1;
     if (use_ws < 0) { const char* e = getenv("QOT_NNCONV_WS"); use_ws = (e && e[0] == '1') ? 1 : 0; }
@@ -953,9 +913,12 @@ extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const flo
                                       float* workspace, int64_t N, int H, int D, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
-    if (H != 64 || D > 4) return QOT_ERR_UNSUPPORTED;      // K*64 floats of GA per row must fit LDS twice per CU
+    if ((H != 16 && H != 32 && H != 64 && H != 128 && H != 256) || D > 4) return QOT_ERR_UNSUPPORTED;
     if (!grad_out || !x || !w1 || !b1 || !invdeg || !b_perm || !gw1 || !gb1 || !workspace || (ld_g & 3) || (ld_x & 3))
         return QOT_ERR_BADARG;
+    if (H != 64)     // other widths: GA built 32 input channels at a time (nnconv_gen.hip)
+        return qot_nnconv_gradh_gen_launch(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col, eid, invdeg, b_perm,
+                                           gw1, gb1, workspace, N, H, D, stream);
     int grid = grid_for(N > 0 ? N : 1, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     const int K = 2 * D;

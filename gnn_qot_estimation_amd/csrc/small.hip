@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256) void table_project_bwd_kernel(const float* __r
     }
 }
 
-// ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]] ------------------------------------------
+// ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]] (0 where idx[i] < 0) ------------------------------------------
 __global__ void gather3_kernel(const float* __restrict__ s0, int n0, const float* __restrict__ s1, int n1,
                                const float* __restrict__ s2, const int32_t* __restrict__ idx, float* __restrict__ out,
                                int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int v = idx[i];
-    out[i] = v < n0 ? s0[v] : (v < n0 + n1 ? s1[v - n0] : s2[v - n0 - n1]);
+    const int v = idx[i];          // v < 0: a padding slot (zero)
+    out[i] = v < 0 ? 0.f : (v < n0 ? s0[v] : (v < n0 + n1 ? s1[v - n0] : s2[v - n0 - n1]));
 }
 
 // ---- table-mode index maps in one launch: ids32 = (int) node_ids ; colf = ids[col] ; colf_t = ids[col_t]

@@ -406,8 +406,50 @@ def nnconv_pack_operands(w2, b2, wroot, k: int):
     return packed[:n_f], packed[n_f:n_f + n_a], packed[n_f + n_a:]
 
 
-def _fused_ok(hin, hout):
-    return hin == 64 and hout == 64
+GEN_WIDTHS = (16, 32, 128, 256)       # csrc/nnconv_gen.hip; 64 has its own tuned kernels (csrc/nnconv_mfma.hip)
+
+
+def nnconv_gen_indices(h: int, k: int, device):
+    """As ``nnconv_fused_indices`` for the width-generic kernels: gather indices into
+    ``cat([nn.2.weight.flatten(), nn.2.bias, lin.weight.flatten()])`` (-1 = zero padding) giving Wcat and WcatT in
+    the per-pass fragment order of ``nnconv_gen_kernel`` and Wk^T in that of ``nnconv_gradh_gen_kernel``
+    (layouts: csrc/nnconv_gen.hip).  Host-side index composition, done once per (width, edge_dim)."""
+    key = ("genidx", h, k, str(device))
+    if key not in _PERM_CACHE:
+        cw = min(h, 64)
+        n_pass, ncb, gall = h // cw, (h + 31) // 32, (k + 2) * cw // 8
+        P_, CB, G_, L_, R_ = torch.meshgrid(torch.arange(n_pass), torch.arange(ncb), torch.arange(gall), torch.arange(64),
+                                            torch.arange(4), indexing="ij")
+        kl = 8 * G_ + 2 * R_ + (L_ >> 5)                 # local inner index of the pass
+        kk, a = kl // cw, P_ * cw + kl % cw              # block, channel
+        col = CB * 32 + (L_ & 31)
+
+        def wcat_off(kk, a, o):                          # offset of Wcat[kk*h + a][o] in the flat parameter triple
+            return torch.where(kk < k, (a * h + o) * k + kk,
+                               torch.where(kk == k, h * h * k + a * h + o, h * h * (k + 1) + o * h + a))
+        pad = col >= h
+        colc = col.clamp(max=h - 1)
+        fwd = torch.where(pad, torch.full_like(col, -1), wcat_off(kk, a, colc))
+        adj = torch.where(pad, torch.full_like(col, -1), wcat_off(kk, colc, a))      # WcatT[kk*h + a][o] = Wcat[kk*h + o][a]
+        cwg = min(h, 32)
+        npg, nbg, gh_ = h // cwg, k * cwg // 32, h // 8
+        P2, NB, GQ, L2, R2 = torch.meshgrid(torch.arange(npg), torch.arange(nbg), torch.arange(gh_), torch.arange(64),
+                                            torch.arange(4), indexing="ij")
+        o = 8 * GQ + 2 * R2 + (L2 >> 5)
+        n = NB * 32 + (L2 & 31)
+        kq, al = n // cwg, n % cwg
+        gh = ((P2 * cwg + al) * h + o) * k + kq
+        allidx = torch.cat([fwd.reshape(-1), adj.reshape(-1), gh.reshape(-1)]).to(torch.int32).contiguous().to(device)
+        _PERM_CACHE[key] = (allidx, fwd.numel(), adj.numel(), gh.numel())
+    return _PERM_CACHE[key]
+
+
+def nnconv_pack_operands_gen(w2, b2, wroot, h: int, k: int):
+    """(Wcat, WcatT, Wk^T) in the generic kernels' fragment orders straight from the three parameters: one launch."""
+    allidx, n_f, n_a, n_g = nnconv_gen_indices(h, k, w2.device)
+    packed = torch.empty(allidx.numel(), dtype=torch.float32, device=w2.device)
+    _lib.call("qot_gather3", P(w2), w2.numel(), P(b2), b2.numel(), P(wroot), P(allidx), P(packed), allidx.numel())
+    return packed[:n_f], packed[n_f:n_f + n_a], packed[n_f + n_a:]
 
 
 class NNConvFn(torch.autograd.Function):
@@ -427,22 +469,22 @@ class NNConvFn(torch.autograd.Function):
             raise _lib.QotError("NNConv edge MLP must be Linear(D, 2D) -> ReLU -> Linear(2D, Hin*Hout)")
         if edge_attr.shape != (graph.num_edges_in, D):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
-        wp = wp_adj = bp = None
-        if _fused_ok(hin, hout):
+        if hin != hout:
+            raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
+        if hin != 64 and hin not in GEN_WIDTHS:
+            raise _lib.QotError(f"NNConv HIP path: hidden width {hin} not in (16, 32, 64, 128, 256)")
+        if D > 4:
+            raise _lib.QotError("NNConv HIP path: edge_dim <= 4")
+        # (Wcat, WcatT, Wk^T) in MFMA fragment order; every width runs gather -> LDS tile -> fp32 MFMA, the operand
+        # [N, (K+2)H] never exists in HBM
+        if hin == 64:
             wp, wp_adj, bp = nnconv_pack_operands(w2, b2, wroot, K)
-            out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
-            _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                      P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
-            A = None
         else:
-            A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
-            _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                      P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-            out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
-            if act is not None:              # unfused width: separate activation kernel, same mask
-                pre = out
-                out = torch.empty_like(pre)
-                _lib.call("qot_act_fwd", P(pre), P(out), pre.numel(), *_act_args(act)[1:])
+            wp, wp_adj, bp = nnconv_pack_operands_gen(w2, b2, wroot, hin, K)
+        out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
+        _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                  P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
+        A = None
         ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, out if act is not None else None,
                               act[3] if act is not None else None)
         ctx.graph = graph
@@ -472,55 +514,35 @@ class NNConvFn(torch.autograd.Function):
         hout = wroot.shape[0]
         K, D = w1.shape
         dev = x.device
-        fused_all = _fused_ok(hin, hout) and D <= 4 and wp_adj is not None and not os.environ.get("QOT_SPLIT_NNCONV_BWD")
-        wcat_t = None if fused_all else nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
-        if fused_all:
+        hh = hin * hout
+        if hin == 64 and not os.environ.get("QOT_SPLIT_NNCONV_BWD"):
             # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U
             gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
-            gpar = torch.empty((K + 2) * hout * hin, dtype=torch.float32, device=dev)
+            gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                       P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 1, P(ws), N, hin, D)
-            # already in the parameters' own layouts (no permute / copy kernels)
-            hh = hin * hout
-            gw2, gb2, gwroot = gpar[:hh * K].view(hh, K), gpar[hh * K:hh * (K + 1)], gpar[hh * (K + 1):].view(hout, hin)
         else:
-            if A is None:      # fused forward did not materialise the operand: rebuild it for dW
-                A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=dev)
-                _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
-                          P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
-            gwcat = gemm_tn(A, g)                                # [(K+2)Hin, Hout] = A^T g
-            # grad_x: same aggregation over the transposed graph, then one GEMM
-            if _fused_ok(hin, hout):
-                wp = wcat_t.reshape(-1)[nnconv_perm_index((K + 2) * hout, dev)]
+            # grad_x: the forward kernel over the transposed graph with the per-block transposed weights;
+            # weight gradient: A^T g by slices of the result, the operand gathered 16 channels at a time
+            gx = None
+            if ctx.needs_input_grad[0]:
                 gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
                 _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                          P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp), None, P(gx), N, hout, D,
+                          P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp_adj), None, P(gx), N, hout, D,
                           0, 0.0, 0.0, 0, None)
-            else:
-                U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
-                _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                          P(graph.col_t), P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
-                gx = U @ wcat_t
-            gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
-            gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
-            gwroot = gwcat[(K + 1) * hin:].t()
+            gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.load().qot_nnconv_dw_workspace_floats(N, hin, D), dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_dw", P(x), hin, P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                      P(graph.eid), P(graph.invdeg), P(gpar), P(ws), N, hin, D)
+        # already in the parameters' own layouts (no permute / copy kernels)
+        gw2, gb2, gwroot = gpar[:hh * K].view(hh, K), gpar[hh * K:hh * (K + 1)], gpar[hh * (K + 1):].view(hout, hin)
         # grad of the edge MLP's first layer
-        if hin != hout:
-            raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
-        if _fused_ok(hin, hout) and D <= 4 and bp is not None:
-            gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
-            gb1 = torch.empty(K, dtype=torch.float32, device=dev)
-            ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
-            _lib.call("qot_nnconv_gradh_fused", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr),
-                      P(graph.col), P(graph.eid), P(graph.invdeg), P(bp), P(gw1), P(gb1), P(ws), N, hin, D)
-        else:
-            wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
-            GA = g @ wk.t()                                      # [N, K*Hin]
-            gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
-            gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
-            _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
-                      P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
+        gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
+        gb1 = torch.empty(K, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
+        _lib.call("qot_nnconv_gradh_fused", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr),
+                  P(graph.col), P(graph.eid), P(graph.invdeg), P(bp), P(gw1), P(gb1), P(ws), N, hin, D)
         return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
 
 

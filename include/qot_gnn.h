@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 3
+#define QOT_ABI_VERSION 4
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -178,8 +178,10 @@ int qot_nnconv_agg(const float* x, int ld_x, const float* edge_attr, const float
  * HBM.  w_perm = Wcat ([(K+2)H, H]) permuted into MFMA fragment order (layout documented in
  * csrc/nnconv_mfma.hip).  edge_ids[p] = original edge id of slot p of the index walked (eid for
  * the CSR, eid_t for the CSC).  transpose != 0: adjoint over the CSC with w_perm built from
- * Wcat^T blocks (grad_x).  bias may be NULL.  Returns QOT_ERR_UNSUPPORTED for H != 64 (callers then
- * use qot_nnconv_agg + a library GEMM). */
+ * Wcat^T blocks (grad_x).  bias may be NULL.  H == 64: the tuned tile kernel (csrc/nnconv_mfma.hip), w_perm =
+ * Wcat in its fragment order.  H in {16, 32, 128, 256} (D <= 4): the per-pass tile kernel of csrc/nnconv_gen.hip,
+ * w_perm in ITS layout (one pass per 64 input channels; documented there, built by
+ * functional.nnconv_gen_perm_index); transpose = 2 / 3 selects that kernel for H == 64 too (measurements). */
 int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr, const float* w1,
                      const float* b1, const int32_t* rowptr, const int32_t* col,
                      const int32_t* edge_ids, const float* invdeg, int transpose,
@@ -208,8 +210,9 @@ int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const float* x, int l
                           const int32_t* rowptr_t, const int32_t* col_t, const int32_t* eid_t,
                           const float* invdeg, const float* w_perm, float* grad_x, float* gwcat_t, int param_layout,
                           float* workspace, int64_t N, int H, int D, qot_stream_t stream);
-/* Fused form of {GA = g @ Wk^T ; qot_nnconv_bwd_edge} for H == 64, D <= 4: the GA tile is produced
- * by MFMA into LDS and consumed there.  b_perm: Wk^T in fragment order (csrc/nnconv_mfma.hip).
+/* Fused form of {GA = g @ Wk^T ; qot_nnconv_bwd_edge}, D <= 4: the GA tile is produced by MFMA into LDS and
+ * consumed there.  b_perm: Wk^T in fragment order (H == 64: csrc/nnconv_mfma.hip; H in {16, 32, 128, 256}:
+ * 32 input channels per pass, layout in csrc/nnconv_gen.hip, built by functional.nnconv_gen_gradh_perm_index).
  * workspace: qot_nnconv_gradh_workspace_floats(D) floats.  gw1/gb1 are overwritten. */
 size_t qot_nnconv_gradh_workspace_floats(int D);
 int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const float* x, int ld_x,
@@ -217,6 +220,18 @@ int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const float* x, int 
                            const int32_t* rowptr, const int32_t* col, const int32_t* eid,
                            const float* invdeg, const float* b_perm, float* gw1, float* gb1,
                            float* workspace, int64_t N, int H, int D, qot_stream_t stream);
+/* Weight gradient of NNConv for every supported width (H in {16, 32, 64, 128, 256}, D <= 4) without
+ * materialising the [N, (K+2)H] operand: grad_params = [d nn.2.weight [H*H, K] | d nn.2.bias [H*H] |
+ * d lin.weight [H, H]] (the parameters' own layouts, (2D+2)*H*H floats) = A^T grad_out, with the operand
+ * tile A of 32 destinations gathered into LDS 16 input channels at a time (csrc/nnconv_gen.hip).  x = the
+ * forward input rows; rowptr/col/eid = CSR by destination.  Replaces {qot_nnconv_agg, A^T g GEMM} of
+ * NNConv's autograd (topological_training/models.py:57 under loss.backward(), train.py:115).
+ * workspace: qot_nnconv_dw_workspace_floats(N, H, D) floats.  Fixed summation order. */
+size_t qot_nnconv_dw_workspace_floats(int64_t N, int H, int D);
+int qot_nnconv_dw(const float* x, int ld_x, const float* grad_out, int ld_g, const float* edge_attr,
+                  const float* w1, const float* b1, const int32_t* rowptr, const int32_t* col,
+                  const int32_t* eid, const float* invdeg, float* grad_params, float* workspace, int64_t N,
+                  int H, int D, qot_stream_t stream);
 /* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
  * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
 int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,

@@ -1,0 +1,137 @@
+"""Width-generic fused NNConv kernels (csrc/nnconv_gen.hip) through the C ABI, against an fp64 restatement of the
+operator contract (App. B.2 algebra: out = bias + A @ Wcat) and its autograd: forward, adjoint (grad_x), weight
+gradient in the parameters' layouts, gradient of the edge MLP's first layer.  Cases: random graph, a 300-in-edge hub
+(more edges in one 32-row tile than the per-edge partial buffer holds -> several segments), edge_dim 2, no edges,
+N not a multiple of 32; every supported width, plus the generic kernel at H = 64 beside the tuned one."""
+import pytest
+import torch
+
+from helpers import TOL, rel_err
+from test_gpu_parity import _nnconv_fp64
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(case, H, dev):
+    g = torch.Generator().manual_seed(17 + H)
+    D = 2 if case == "edge_dim2" else 4
+    if case == "hub":
+        N = 500 + 13
+        src = torch.randint(0, N, (300,), generator=g)
+        ei = torch.cat([torch.stack([src, torch.full_like(src, 40)]), torch.randint(0, N, (2, 1500), generator=g)], 1)
+    elif case == "no_edges":
+        N, ei = 70, torch.zeros(2, 0, dtype=torch.long)
+    else:
+        N = 333
+        ei = torch.randint(0, N, (2, 4 * N), generator=g)
+    K = 2 * D
+    E = ei.shape[1]
+    x = torch.randn(N, H, generator=g)
+    ea = torch.rand(max(E, 1), D, generator=g)[:E]
+    w1 = torch.randn(K, D, generator=g); b1 = torch.randn(K, generator=g)
+    w2 = torch.randn(H * H, K, generator=g) / 8; b2 = torch.randn(H * H, generator=g) / 8
+    wroot = torch.randn(H, H, generator=g) / 8
+    bias = torch.randn(H, generator=g)
+    gout = torch.randn(N, H, generator=g)
+    return dict(N=N, E=E, D=D, K=K, ei=ei, x=x, ea=ea, w1=w1, b1=b1, w2=w2, b2=b2, wroot=wroot, bias=bias, gout=gout)
+
+
+def _fp64_autograd(c):
+    """NNConv(aggr='mean') written the PyG way in fp64 ([E, H, H] weights), loss = <out, gout>."""
+    H, K = c["x"].shape[1], c["K"]
+    t = {k: c[k].double().requires_grad_(True) for k in ("x", "w1", "b1", "w2", "b2", "wroot", "bias")}
+    ea, gout, ei, N = c["ea"].double(), c["gout"].double(), c["ei"], c["N"]
+    out = t["x"] @ t["wroot"].t() + t["bias"]
+    if c["E"]:
+        h = torch.relu(ea @ t["w1"].t() + t["b1"])
+        theta = (h @ t["w2"].t() + t["b2"]).view(-1, H, H)
+        msg = torch.bmm(t["x"][ei[0]].unsqueeze(1), theta).squeeze(1)
+        deg = torch.zeros(N, dtype=torch.float64).index_add_(0, ei[1], torch.ones(c["E"], dtype=torch.float64)).clamp(min=1)
+        out = out + torch.zeros(N, H, dtype=torch.float64).index_add_(0, ei[1], msg) / deg[:, None]
+    (out * gout).sum().backward()
+    return out.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in t.items()}
+
+
+@pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("case", ["random", "hub", "edge_dim2", "no_edges"])
+def test_generic_fused_nnconv_kernels_vs_fp64(cuda_device, H, case):
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd import functional as QF
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    P = _lib.ptr
+    dev = cuda_device
+    c = _case(case, H, dev)
+    N, D, K = c["N"], c["D"], c["K"]
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in c.items()}
+    gi = build_graph_index(d["ei"], N)
+    ea = d["ea"] if c["E"] else torch.zeros(1, D, device=dev)
+    ref_out, ref_g = _fp64_autograd(c)
+    if H == 64:
+        wp, wp_adj, bp = QF.nnconv_pack_operands(d["w2"], d["b2"], d["wroot"], K)
+        # the generic kernel's own operand order at H = 64 (selected by transpose = 2 / 3)
+        allidx, n_f, n_a, n_g = QF.nnconv_gen_indices(64, K, dev)
+        flat = torch.cat([d["w2"].reshape(-1), d["b2"], d["wroot"].reshape(-1)])
+        packed = torch.where(allidx < 0, torch.zeros((), device=dev), flat[allidx.long().clamp(min=0)])
+        variants = [(0, 1, wp, wp_adj), (2, 3, packed[:n_f].contiguous(), packed[n_f:n_f + n_a].contiguous())]
+    else:
+        wp, wp_adj, bp = QF.nnconv_pack_operands_gen(d["w2"], d["b2"], d["wroot"], H, K)
+        variants = [(0, 1, wp, wp_adj)]
+    for t_fwd, t_adj, w_f, w_a in variants:
+        out = torch.full((N, H), float("nan"), device=dev)
+        _lib.call("qot_nnconv_fused", P(d["x"]), H, P(ea), P(d["w1"]), P(d["b1"]), P(gi.rowptr), P(gi.col), P(gi.eid),
+                  P(gi.invdeg), t_fwd, P(w_f), P(d["bias"]), P(out), N, H, D, 0, 0.0, 0.0, 0, None)
+        gx = torch.full((N, H), float("nan"), device=dev)
+        _lib.call("qot_nnconv_fused", P(d["gout"]), H, P(ea), P(d["w1"]), P(d["b1"]), P(gi.rowptr_t), P(gi.col_t),
+                  P(gi.eid_t), P(gi.invdeg), t_adj, P(w_a), None, P(gx), N, H, D, 0, 0.0, 0.0, 0, None)
+        torch.cuda.synchronize()
+        assert rel_err(out, ref_out) <= TOL, ("fwd", t_fwd)
+        assert rel_err(gx, ref_g["x"]) <= TOL, ("adjoint", t_adj)
+    # weight gradient in the parameters' layouts
+    gpar = torch.full(((K + 2) * H * H,), float("nan"), device=dev)
+    ws = torch.empty(_lib.load().qot_nnconv_dw_workspace_floats(N, H, D), device=dev)
+    _lib.call("qot_nnconv_dw", P(d["x"]), H, P(d["gout"]), H, P(ea), P(d["w1"]), P(d["b1"]), P(gi.rowptr), P(gi.col),
+              P(gi.eid), P(gi.invdeg), P(gpar), P(ws), N, H, D)
+    hh = H * H
+    scale = max(float(ref_g[k].abs().max()) for k in ("w2", "b2", "wroot"))
+    for name, got in (("w2", gpar[:hh * K].view(hh, K)), ("b2", gpar[hh * K:hh * (K + 1)]), ("wroot", gpar[hh * (K + 1):].view(H, H))):
+        e = float((got.double().cpu() - ref_g[name]).abs().max() / max(float(ref_g[name].abs().max()), 1e-3 * scale))
+        assert e <= TOL, (name, e)
+    # first edge-MLP layer
+    gw1 = torch.full((K, D), float("nan"), device=dev); gb1 = torch.full((K,), float("nan"), device=dev)
+    wsh = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), device=dev)
+    _lib.call("qot_nnconv_gradh_fused", P(d["gout"]), H, P(d["x"]), H, P(ea), P(d["w1"]), P(d["b1"]), P(gi.rowptr),
+              P(gi.col), P(gi.eid), P(gi.invdeg), P(bp), P(gw1), P(gb1), P(wsh), N, H, D)
+    torch.cuda.synchronize()
+    if c["E"]:
+        assert rel_err(gw1, ref_g["w1"]) <= TOL and rel_err(gb1, ref_g["b1"]) <= TOL
+    else:
+        assert float(gw1.abs().max()) == 0.0 and float(gb1.abs().max()) == 0.0
+    # bitwise run-to-run (fixed summation orders everywhere)
+    gpar2 = torch.empty_like(gpar)
+    _lib.call("qot_nnconv_dw", P(d["x"]), H, P(d["gout"]), H, P(ea), P(d["w1"]), P(d["b1"]), P(gi.rowptr), P(gi.col),
+              P(gi.eid), P(gi.invdeg), P(gpar2), P(ws), N, H, D)
+    assert torch.equal(gpar, gpar2)
+
+
+@pytest.mark.parametrize("H", [16, 128])
+def test_generic_nnconv_dropout_mask_matches_act_kernels(cuda_device, H):
+    """The fused leaky_relu + dropout epilogue of the generic kernel draws the same mask as qot_act_fwd / qot_act_bwd."""
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd import functional as QF
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    P = _lib.ptr
+    dev = cuda_device
+    c = _case("random", H, dev)
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in c.items()}
+    N, D, K = c["N"], c["D"], c["K"]
+    gi = build_graph_index(d["ei"], N)
+    wp, _, _ = QF.nnconv_pack_operands_gen(d["w2"], d["b2"], d["wroot"], H, K)
+    step = torch.tensor([5], dtype=torch.int64, device=dev)
+    pre, fused, sep = (torch.empty(N, H, device=dev) for _ in range(3))
+    args = (P(d["x"]), H, P(d["ea"]), P(d["w1"]), P(d["b1"]), P(gi.rowptr), P(gi.col), P(gi.eid), P(gi.invdeg), 0, P(wp),
+            P(d["bias"]))
+    _lib.call("qot_nnconv_fused", *args, P(pre), N, H, D, 0, 0.0, 0.0, 0, None)
+    _lib.call("qot_nnconv_fused", *args, P(fused), N, H, D, 1, 0.01, 0.4, 99, P(step))
+    _lib.call("qot_act_fwd", P(pre), P(sep), pre.numel(), 0.01, 0.4, 99, P(step))
+    torch.cuda.synchronize()
+    assert torch.equal(fused, sep)
