@@ -385,8 +385,12 @@ def fit(model, dataset, *, kind: str = "topological", batch_size: int = 512, num
 def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: str = "topological",
              batch_size: int = 512, output_dim: int = 3, device="cuda",
              output_keys: Sequence[str] = ("osnr", "snr", "ber"),
-             target_ranges: Dict[str, Dict[str, float]] = TARGET_RANGES) -> Dict[str, Dict[str, float]]:
-    """test.py's metric block: per-output R2 and MSE on min-max descaled values (test.py:76-121)."""
+             target_ranges: Dict[str, Dict[str, float]] = TARGET_RANGES, return_predictions: bool = False):
+    """test.py's metric block: per-output R2 and MSE on min-max descaled values (test.py:76-121).
+
+    ``return_predictions``: also return ``(y_true_descaled, y_pred_descaled, skipped_graphs)`` -- the arrays test.py
+    writes to ``y_true_descaled.json`` / ``y_pred_descaled.json`` (test.py:92-103,129-136), in dataset order; they stay
+    on the device until the loop is over (one host copy)."""
     device = torch.device(device)
     model.to(device)
     idx = range(len(dataset)) if indices is None else indices
@@ -396,21 +400,37 @@ def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: s
     rank, world = _rank_world()
     loader = GraphLoader(dataset, batch_size, shuffle=False, device=device,
                          batches=_local_batches(idx, batch_size, rank, world))
+    kept, skipped = [], 0
     with torch.no_grad():
-        for data in loader:
+        for b, data in enumerate(loader):
             if data is None:
                 continue
             try:
                 out, y = fwd(model, data, output_dim)
             except ValueError:
+                skipped += data.num_graphs            # lightpath_training/test.py:82-85
                 continue
             stats.update(y, out)
+            if return_predictions:
+                kept.append((b, y.detach().clone(), out.detach().clone()))
     stats.all_reduce()
-    scale = torch.tensor([target_ranges[k]["max"] - target_ranges[k]["min"] for k in output_keys][:output_dim],
-                         dtype=torch.float64)
+    keys = list(output_keys)[:output_dim]
+    scale = torch.tensor([target_ranges[k]["max"] - target_ranges[k]["min"] for k in keys], dtype=torch.float64)
     res = stats.result(scale)
-    return {k.upper(): {"R2": res["r2_raw"][i], "Test_MSE": res["mse_raw"][i]}
-            for i, k in enumerate(list(output_keys)[:output_dim])}
+    metrics = {k.upper(): {"R2": res["r2_raw"][i], "Test_MSE": res["mse_raw"][i]} for i, k in enumerate(keys)}
+    if not return_predictions:
+        return metrics
+    parts = [(b, rank, y.cpu(), o.cpu()) for b, y, o in kept]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (parts, skipped))
+        parts = sorted((p for ps, _ in gathered for p in ps), key=lambda t: (t[0], t[1]))
+        skipped = sum(sk for _, sk in gathered)
+    lo = torch.tensor([target_ranges[k]["min"] for k in keys], dtype=torch.float64)
+    cat = lambda j: (torch.cat([p[j].double() for p in parts]) if parts else torch.zeros(0, output_dim, dtype=torch.float64))
+    y_true = cat(2) * scale + lo                      # min_max_descale (test.py:12-13)
+    y_pred = cat(3) * scale + lo
+    return metrics, y_true, y_pred, skipped
 
 
 def next_model_path(root_dir: str) -> Tuple[str, int]:
