@@ -14,7 +14,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqot_gnn.so")
+# QOT_LIB_PATH: a diagnostic build (csrc `make DIAG=1 OUT=...`, tools/ablate_*.py); never set in production
+LIB_PATH = os.environ.get("QOT_LIB_PATH") or os.path.join(_HERE, "libqot_gnn.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 _p = C.c_void_p

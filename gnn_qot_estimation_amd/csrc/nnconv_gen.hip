@@ -68,7 +68,7 @@ __device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx,
     const bool upper = (sub & 4) != 0;
     for (int base = beg; base < end; base += 8) {
         const int p = base + sub;
-        int myj = 0;
+        int myj = (int)i;
         float myh[K], mysc = 0.f;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
@@ -88,6 +88,9 @@ __device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx,
             }
         }
         const int cnt = (end - base < 8) ? end - base : 8;
+        // dead slots of a batch (lane p >= end) carry h = 0 and scale = 0 from the prefetch above, so their terms vanish
+        // without per-use selects; their row load is pointed at the destination's own row (always a valid address, and
+        // a non-finite value there already reaches this destination through its root term)
 #define QOT_GEN_EDGE4(U0)                                                                                \
         {                                                                                                \
             float xv[4][CPL];                                                                            \
@@ -97,19 +100,14 @@ __device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx,
             jj[2] = group8_bcast<U0 + 2>(myj, upper); jj[3] = group8_bcast<U0 + 3>(myj, upper);          \
             sc[0] = group8_bcast<U0 + 0>(mysc, upper); sc[1] = group8_bcast<U0 + 1>(mysc, upper);        \
             sc[2] = group8_bcast<U0 + 2>(mysc, upper); sc[3] = group8_bcast<U0 + 3>(mysc, upper);        \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const bool live = U0 + u < cnt;                                                          \
-                ldv<CPL>(x + (live ? (int64_t)jj[u] : 0) * ldx + cbase, xv[u]);                          \
-                if (!live) sc[u] = 0.f;                                                                  \
-            }                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
+                ldv<CPL>(x + (int64_t)jj[u] * ldx + cbase, xv[u]);                                       \
             _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                           \
                 float h[4];                                                                              \
                 h[0] = group8_bcast<U0 + 0>(myh[kk], upper); h[1] = group8_bcast<U0 + 1>(myh[kk], upper);  \
                 h[2] = group8_bcast<U0 + 2>(myh[kk], upper); h[3] = group8_bcast<U0 + 3>(myh[kk], upper);  \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                    const float hv = (U0 + u < cnt) ? h[u] : 0.f;                                        \
-                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(hv, xv[u][c], acc[kk][c]); \
-                }                                                                                        \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u)                                            \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h[u], xv[u][c], acc[kk][c]); \
             }                                                                                            \
             _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
                 _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
@@ -167,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ ea, const float* __restrict__ w1,
     const float* __restrict__ b1, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, const float* __restrict__ Wp,
-    const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act) {
+    const float* __restrict__ bias, float* __restrict__ out, int64_t N, ActParams act, int variant) {
+    // variant (diagnostic builds only, tools/ablate_gen.py): 1 = no gather (constant operand tile), 2 = weight
+    // fragments loaded once (no L2 stream), 3 = gather only (no MFMA), 4 = 1 + 2
     using G = GenW<H>;
     constexpr int K = 2 * D;
     constexpr int CW = G::CW, NP = G::NP, CPL = G::CPL, NCB = G::NCB, CBW = G::CBW, KS = G::KS;
@@ -207,6 +207,16 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
             float root[CPL];
             {
                 float acc[K + 1][CPL];
+#ifdef QOT_DIAG
+                if (variant == 1 || variant == 4) {
+#pragma unroll
+                    for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+                        for (int c_ = 0; c_ < CPL; ++c_) acc[kk][c_] = 1.0f + kk;
+#pragma unroll
+                    for (int c_ = 0; c_ < CPL; ++c_) root[c_] = 1.0f;
+                } else
+#endif
                 gen_gather<D, CPL, TRANSPOSE>(x, ldx, p * CW + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N,
                                               0, 0x7fffffff, acc, root);
 #pragma unroll
@@ -214,20 +224,26 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
                 if (ROOT_LDS) frag_store<CW, CPL>(At, K + 1, sub, il, root);
             }
             __syncthreads();
+#ifdef QOT_DIAG
+            if (variant == 3) { lds_barrier(); continue; }
+            const int64_t gstep = (variant == 2 || variant == 4) ? 0 : 1;      // 0: every fragment load hits the same line
+#else
+            constexpr int64_t gstep = 1;
+#endif
             // ---- main part: this wave's groups [ks*GS, (ks+1)*GS) against its column blocks
             const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)(p * NCB + cb0) * GALL + ks * GS) * 64 + lane;
             float4 bc[CBW][CH], bn[CBW][CH];
 #pragma unroll
             for (int q = 0; q < CBW; ++q)
 #pragma unroll
-                for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + u) * 64];
+                for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + u) * 64 * gstep];
             int ch = 0;
 #pragma unroll 1
             for (; ch + 1 < NCH; ch += 2) {
 #pragma unroll
                 for (int q = 0; q < CBW; ++q)
 #pragma unroll
-                    for (int u = 0; u < CH; ++u) bn[q][u] = wp[((int64_t)q * GALL + (ch + 1) * CH + u) * 64];
+                    for (int u = 0; u < CH; ++u) bn[q][u] = wp[((int64_t)q * GALL + (ch + 1) * CH + u) * 64 * gstep];
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
                     const float4 a = At4[at4_slot(ks * GS + ch * CH + u, hi, r31)];
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
 #pragma unroll
                     for (int q = 0; q < CBW; ++q)
 #pragma unroll
-                        for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + (ch + 2) * CH + u) * 64];
+                        for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + (ch + 2) * CH + u) * 64 * gstep];
                 }
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg, const float* __restrict__ ea,
     const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
-    float* __restrict__ slabs, int64_t N, int nsplit) {
+    float* __restrict__ slabs, int64_t N, int nsplit, int variant) {
     using W = DwW<H>;
     constexpr int K = 2 * D;
     constexpr int AC = W::AC, NAC = W::NAC, OC = W::OC, OCB = W::OCB, NSLICE = W::NSLICE;
@@ -396,12 +412,22 @@ __global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
             }
         }
         float acc[K + 1][2], root[2];
+#ifdef QOT_DIAG
+        if (variant == 1) {
+#pragma unroll
+            for (int kk = 0; kk <= K; ++kk) { acc[kk][0] = 1.f + kk; acc[kk][1] = 2.f; }
+            root[0] = root[1] = 1.f;
+        } else
+#endif
         gen_gather<D, 2, false>(x, ldx, a0 + 2 * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, 0, 0x7fffffff, acc, root);
 #pragma unroll
         for (int kk = 0; kk <= K; ++kk)
             *reinterpret_cast<float2*>(&Atile[il * ROWS + kk * AC + 2 * sub]) = make_float2(acc[kk][0], acc[kk][1]);
         *reinterpret_cast<float2*>(&Atile[il * ROWS + (K + 1) * AC + 2 * sub]) = make_float2(root[0], root[1]);
         __syncthreads();
+#ifdef QOT_DIAG
+        if (variant == 3) { lds_barrier(); continue; }
+#endif
         // dW[(kk,a), o] += sum over the tile's nodes: A operand = the tile read transposed (node = k index)
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
@@ -656,20 +682,30 @@ using namespace qot;
         default: return QOT_ERR_UNSUPPORTED;                     \
     }
 
+#ifdef QOT_DIAG
+static int g_gen_variant = 0;
+extern "C" void qot_debug_gen_variant(int v) { g_gen_variant = v; }
+#endif
+
 // Width-generic form of qot_nnconv_fused (same arguments; w_perm in the per-pass layout documented above).
 int qot_nnconv_gen_launch(const float* x, int ld_x, const float* edge_attr, const float* w1, const float* b1,
                           const int32_t* rowptr, const int32_t* col, const int32_t* edge_ids, const float* invdeg,
                           int transpose, const float* w_perm, const float* bias, float* out, int64_t N, int H, int D,
                           const ActParams& ap, hipStream_t stream) {
+#ifdef QOT_DIAG
+    const int variant = g_gen_variant;
+#else
+    const int variant = 0;
+#endif
     int grid = grid_for(N, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
         if (transpose)
             nnconv_gen_kernel<kH, kD, true><<<grid, 256, 0, stream>>>(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids,
-                                                                       invdeg, w_perm, bias, out, N, ap);
+                                                                       invdeg, w_perm, bias, out, N, ap, variant);
         else
             nnconv_gen_kernel<kH, kD, false><<<grid, 256, 0, stream>>>(x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids,
-                                                                        invdeg, w_perm, bias, out, N, ap);
+                                                                        invdeg, w_perm, bias, out, N, ap, variant);
     }));
     QOT_LAUNCH_CHECK();
     return QOT_OK;
@@ -714,9 +750,14 @@ extern "C" int qot_nnconv_dw(const float* x, int ld_x, const float* grad_out, in
     const int ns = dw_nslice(H);
     if (!ns) return QOT_ERR_UNSUPPORTED;
     const int nsplit = dw_splits(N, ns);
+#ifdef QOT_DIAG
+    const int variant = g_gen_variant;
+#else
+    const int variant = 0;
+#endif
     QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
         nnconv_dw_gen_kernel<kH, kD><<<nsplit * ns, 256, 0, stream>>>(x, ld_x, grad_out, ld_g, edge_attr, w1, b1, rowptr,
-                                                                      col, eid, invdeg, workspace, N, nsplit);
+                                                                      col, eid, invdeg, workspace, N, nsplit, variant);
         QOT_LAUNCH_CHECK();
         const int64_t elems = (int64_t)(2 * kD + 2) * kH * kH;
         nnconv_dw_final_kernel<kH><<<grid_for(elems, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);

@@ -409,14 +409,14 @@ def nnconv_pack_operands(w2, b2, wroot, k: int):
 GEN_WIDTHS = (16, 32, 128, 256)       # csrc/nnconv_gen.hip; 64 has its own tuned kernels (csrc/nnconv_mfma.hip)
 
 
-def nnconv_gen_indices(h: int, k: int, device):
+def nnconv_gen_indices(h: int, k: int, device, cw: int = 0):
     """As ``nnconv_fused_indices`` for the width-generic kernels: gather indices into
     ``cat([nn.2.weight.flatten(), nn.2.bias, lin.weight.flatten()])`` (-1 = zero padding) giving Wcat and WcatT in
     the per-pass fragment order of ``nnconv_gen_kernel`` and Wk^T in that of ``nnconv_gradh_gen_kernel``
     (layouts: csrc/nnconv_gen.hip).  Host-side index composition, done once per (width, edge_dim)."""
-    key = ("genidx", h, k, str(device))
+    key = ("genidx", h, k, str(device), cw)
     if key not in _PERM_CACHE:
-        cw = min(h, 64)
+        cw = cw or min(h, 64)            # input channels per pass (32: the three-workgroups-per-CU variant)
         n_pass, ncb, gall = h // cw, (h + 31) // 32, (k + 2) * cw // 8
         P_, CB, G_, L_, R_ = torch.meshgrid(torch.arange(n_pass), torch.arange(ncb), torch.arange(gall), torch.arange(64),
                                             torch.arange(4), indexing="ij")
