@@ -20,51 +20,123 @@ struct GatCfg {
     static constexpr int LPH = (C / 4 < TPR) ? C / 4 : TPR;  // lanes that share one head
 };
 
+// Attention logits from the projected rows (App. B.3): a_src[n,h] = <z[n,h,:], att_src[h,:]>, a_dst likewise.
+// One pass over z; a head's channels sit on LPH consecutive lanes of one float4 slot, so the reduction is a
+// DPP / shuffle butterfly inside that lane group.
+template <int HEADS, int C>
+__global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict__ z, const float* __restrict__ att_src,
+                                                         const float* __restrict__ att_dst, float* __restrict__ a_src,
+                                                         float* __restrict__ a_dst, int64_t N) {
+    using G = GatCfg<HEADS, C>;
+    const int sub = threadIdx.x % G::TPR;
+    const int64_t i = (int64_t)blockIdx.x * G::RPB + threadIdx.x / G::TPR;
+    if (i >= N) return;
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) {
+        const int c = 4 * (sub + G::TPR * v);
+        const float4 zv = ld4(z + i * G::HC + c);
+        const float ps = group_sum<G::LPH>(dot4(zv, ld4(att_src + c)));
+        const float pd = group_sum<G::LPH>(dot4(zv, ld4(att_dst + c)));
+        if (c % C == 0) { a_src[i * HEADS + c / C] = ps; a_dst[i * HEADS + c / C] = pd; }
+    }
+}
+
+// Forward.  Every workgroup walks a contiguous chunk of destinations (slot s takes rows r0+s, r0+s+RPB, ...), two
+// in-edges in flight per lane group.  bn_partials != NULL: per-workgroup column sums of (out - bias) and its square
+// land in partials[blk][2][HC] -- the BatchNorm that follows (lightpath_training/models.py:31) gets its batch
+// statistics without another pass over the [N, 4C] matrix (shift = bias keeps the sums centred).
 template <int HEADS, int C>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ bias, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, float* __restrict__ out, float* __restrict__ stats, int64_t N,
-    float ns) {
+    float ns, float* __restrict__ bn_partials) {
     using G = GatCfg<HEADS, C>;
+    __shared__ float4 red1[256];
+    __shared__ float4 red2[256];
     const int sub = threadIdx.x % G::TPR;
-    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
-    if (i >= N) return;
+    const int slot = threadIdx.x / G::TPR;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + G::RPB - 1) / G::RPB * G::RPB;
+    const int64_t r0 = (int64_t)blk * chunk;
+    const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
     int hh[G::NV];
-    float ad[G::NV], m[G::NV], l[G::NV];
-    float4 acc[G::NV];
+    float4 bz[G::NV], s1[G::NV], s2[G::NV];
 #pragma unroll
     for (int v = 0; v < G::NV; ++v) {
         hh[v] = (4 * (sub + G::TPR * v)) / C;
-        ad[v] = a_dst[i * HEADS + hh[v]];
-        m[v] = -INFINITY;
-        l[v] = 0.f;
-        acc[v] = f4zero();
+        bz[v] = ld4(bias + 4 * (sub + G::TPR * v));
+        s1[v] = f4zero(); s2[v] = f4zero();
     }
-    const int beg = rowptr[i], end = rowptr[i + 1];
-    for (int p = beg; p < end; ++p) {
-        const int64_t j = col[p];
+    for (int64_t i = r0 + slot; i < r1; i += G::RPB) {
+        float ad[G::NV], m[G::NV], l[G::NV];
+        float4 acc[G::NV];
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
-            float4 zj = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
-            float raw = a_src[j * HEADS + hh[v]] + ad[v];
-            float s = raw > 0.f ? raw : ns * raw;
-            float mn = fmaxf(m[v], s);
-            float sc = __expf(m[v] - mn);
-            float pe = __expf(s - mn);
-            l[v] = fmaf(l[v], sc, pe);
-            acc[v] = fma4(pe, zj, scale4(sc, acc[v]));
-            m[v] = mn;
+            ad[v] = a_dst[i * HEADS + hh[v]];
+            m[v] = -INFINITY;
+            l[v] = 0.f;
+            acc[v] = f4zero();
+        }
+        const int beg = rowptr[i], end = rowptr[i + 1];
+        for (int p = beg; p < end; p += 2) {
+            const bool two = p + 1 < end;
+            const int64_t j0 = col[p];
+            const int64_t j1 = two ? col[p + 1] : j0;
+            float4 z0[G::NV], z1[G::NV];
+            float as0[G::NV], as1[G::NV];
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) {
+                z0[v] = ld4(z + j0 * G::HC + 4 * (sub + G::TPR * v));
+                z1[v] = ld4(z + j1 * G::HC + 4 * (sub + G::TPR * v));
+                as0[v] = a_src[j0 * HEADS + hh[v]];
+                as1[v] = a_src[j1 * HEADS + hh[v]];
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e == 1 && !two) break;
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    const float4 zj = e ? z1[v] : z0[v];
+                    const float raw = (e ? as1[v] : as0[v]) + ad[v];
+                    const float s = raw > 0.f ? raw : ns * raw;
+                    const float mn = fmaxf(m[v], s);
+                    const float sc = __expf(m[v] - mn);
+                    const float pe = __expf(s - mn);
+                    l[v] = fmaf(l[v], sc, pe);
+                    acc[v] = fma4(pe, zj, scale4(sc, acc[v]));
+                    m[v] = mn;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            const int c = 4 * (sub + G::TPR * v);
+            const float denom = l[v] + 1e-16f;
+            const float4 d = scale4(1.0f / denom, acc[v]);            // out - bias
+            st4(out + i * G::HC + c, add4(d, bz[v]));
+            s1[v] = add4(s1[v], d);
+            s2[v] = make_float4(fmaf(d.x, d.x, s2[v].x), fmaf(d.y, d.y, s2[v].y), fmaf(d.z, d.z, s2[v].z), fmaf(d.w, d.w, s2[v].w));
+            if (c % C == 0) {
+                stats[(i * HEADS + hh[v]) * 2] = (beg < end) ? m[v] : 0.f;
+                stats[(i * HEADS + hh[v]) * 2 + 1] = denom;
+            }
         }
     }
+    if (bn_partials) {          // fixed order: slots 0..RPB-1 of this workgroup, then the workgroups in bn_finalize
 #pragma unroll
-    for (int v = 0; v < G::NV; ++v) {
-        const int c = 4 * (sub + G::TPR * v);
-        const float denom = l[v] + 1e-16f;
-        st4(out + i * G::HC + c, add4(scale4(1.0f / denom, acc[v]), ld4(bias + c)));
-        if (c % C == 0) {
-            stats[(i * HEADS + hh[v]) * 2] = (beg < end) ? m[v] : 0.f;
-            stats[(i * HEADS + hh[v]) * 2 + 1] = denom;
+        for (int v = 0; v < G::NV; ++v) {
+            __syncthreads();
+            red1[threadIdx.x] = s1[v];
+            red2[threadIdx.x] = s2[v];
+            __syncthreads();
+            if (slot == 0) {
+                float4 a = red1[sub], b = red2[sub];
+                for (int k = 1; k < G::RPB; ++k) { a = add4(a, red1[k * G::TPR + sub]); b = add4(b, red2[k * G::TPR + sub]); }
+                const int c = 4 * (sub + G::TPR * v);
+                st4(bn_partials + ((int64_t)blk * 2) * G::HC + c, a);
+                st4(bn_partials + ((int64_t)blk * 2 + 1) * G::HC + c, b);
+            }
         }
     }
 }
@@ -132,7 +204,9 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
     const int32_t* __restrict__ pos_t, float* __restrict__ gz, float* __restrict__ gas, int64_t N,
-    float ns) {
+    float ns, const float* __restrict__ att_src, const float* __restrict__ att_dst, const float* __restrict__ gad) {
+    // att_src != NULL: the logits were formed from z inside the operator (gat_logits_kernel), so their gradient
+    // flows back into grad_z here: + grad_a_src[j,h] att_src[h,:] + grad_a_dst[j,h] att_dst[h,:]
     using G = GatCfg<HEADS, C>;
     const int sub = threadIdx.x % G::TPR;
     const int64_t j = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
@@ -164,9 +238,71 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(
 #pragma unroll
     for (int v = 0; v < G::NV; ++v) {
         const int c = 4 * (sub + G::TPR * v);
-        st4(gz + j * G::HC + c, acc[v]);
+        float4 o = acc[v];
+        if (att_src) {
+            o = fma4(sds[v], ld4(att_src + c), o);
+            o = fma4(gad[j * HEADS + hh[v]], ld4(att_dst + c), o);
+        }
+        st4(gz + j * G::HC + c, o);
         if (c % C == 0) gas[j * HEADS + hh[v]] = sds[v];
     }
+}
+
+// grad of the attention vectors: gatt_src[h,c] = sum_n grad_a_src[n,h] z[n,h,c] (gatt_dst with grad_a_dst): per-workgroup
+// column partials [blk][2][HC], summed in a fixed order by gat_att_grad_final_kernel.
+template <int HEADS, int C>
+__global__ __launch_bounds__(256) void gat_att_grad_kernel(const float* __restrict__ z, const float* __restrict__ gas,
+                                                           const float* __restrict__ gad, float* __restrict__ partials,
+                                                           int64_t N) {
+    using G = GatCfg<HEADS, C>;
+    __shared__ float4 red1[256];
+    __shared__ float4 red2[256];
+    const int sub = threadIdx.x % G::TPR;
+    const int slot = threadIdx.x / G::TPR;
+    const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + G::RPB - 1) / G::RPB * G::RPB;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk;
+    const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
+    float4 s1[G::NV], s2[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) { s1[v] = f4zero(); s2[v] = f4zero(); }
+    for (int64_t i = r0 + slot; i < r1; i += G::RPB) {
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            const int c = 4 * (sub + G::TPR * v);
+            const float4 zv = ld4(z + i * G::HC + c);
+            s1[v] = fma4(gas[i * HEADS + c / C], zv, s1[v]);
+            s2[v] = fma4(gad[i * HEADS + c / C], zv, s2[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) {
+        __syncthreads();
+        red1[threadIdx.x] = s1[v];
+        red2[threadIdx.x] = s2[v];
+        __syncthreads();
+        if (slot == 0) {
+            float4 a = red1[sub], b = red2[sub];
+            for (int k = 1; k < G::RPB; ++k) { a = add4(a, red1[k * G::TPR + sub]); b = add4(b, red2[k * G::TPR + sub]); }
+            const int c = 4 * (sub + G::TPR * v);
+            st4(partials + ((int64_t)blockIdx.x * 2) * G::HC + c, a);
+            st4(partials + ((int64_t)blockIdx.x * 2 + 1) * G::HC + c, b);
+        }
+    }
+}
+
+__global__ void gat_att_grad_final_kernel(const float* __restrict__ partials, int nblk, int HC, float* __restrict__ gsrc,
+                                          float* __restrict__ gdst) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per column
+    if (c >= HC) return;
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < nblk; k += 64) {
+        a += (double)partials[((int64_t)k * 2) * HC + c];
+        b += (double)partials[((int64_t)k * 2 + 1) * HC + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane == 0) { gsrc[c] = (float)a; gdst[c] = (float)b; }
 }
 
 }  // namespace qot
@@ -186,16 +322,49 @@ using namespace qot;
         default: return QOT_ERR_UNSUPPORTED;                               \
     }
 
+static int gat_blocks(int64_t N, int rpb) {
+    int64_t b = (N + rpb - 1) / rpb;
+    const int64_t cap = 2048;          // >= 8 workgroups per CU; each folds its rows' BatchNorm partials
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+extern "C" size_t qot_gat_bn_partials_floats(int64_t N, int heads, int C) {
+    return (size_t)2048 * 2 * (size_t)(heads * C);
+}
+
+// number of workgroups qot_gat_fwd / qot_gat_att_grad launch = rows of their partials buffers
+extern "C" int qot_gat_blocks(int64_t N, int heads, int C) {
+    if (heads != 4 || C <= 0) return 0;
+    const int hc4 = heads * C / 4;
+    const int tpr = hc4 < 64 ? hc4 : 64;
+    return gat_blocks(N, 256 / tpr);
+}
+
+extern "C" int qot_gat_logits(const float* z, const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                              int64_t N, int heads, int C, qot_stream_t stream) {
+    if (N < 0) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!z || !att_src || !att_dst || !a_src || !a_dst) return QOT_ERR_BADARG;
+    QOT_DISPATCH_GAT(heads, C, {
+        using G = GatCfg<4, kC>;
+        gat_logits_kernel<4, kC><<<grid_for(N, G::RPB), 256, 0, (hipStream_t)stream>>>(z, att_src, att_dst, a_src, a_dst, N);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" int qot_gat_fwd(const float* z, const float* a_src, const float* a_dst, const float* bias,
                            const int32_t* rowptr, const int32_t* col, float* out, float* stats,
-                           int64_t N, int heads, int C, float neg_slope, qot_stream_t stream) {
+                           int64_t N, int heads, int C, float neg_slope, float* bn_partials,
+                           qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!z || !a_src || !a_dst || !bias || !col || !out || !stats) return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        gat_fwd_kernel<4, kC><<<grid_for(N, G::RPB), 256, 0, (hipStream_t)stream>>>(
-            z, a_src, a_dst, bias, rowptr, col, out, stats, N, neg_slope);
+        const int nblk = gat_blocks(N, G::RPB);
+        gat_fwd_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(
+            z, a_src, a_dst, bias, rowptr, col, out, stats, N, neg_slope, bn_partials);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;
@@ -222,16 +391,35 @@ extern "C" int qot_gat_bwd_src(const float* grad_out, const float* a_src, const 
                                const float* escr, const float* delta, const int32_t* rowptr_t,
                                const int32_t* col_t, const int32_t* pos_t, float* grad_z,
                                float* grad_a_src, int64_t N, int heads, int C, float neg_slope,
+                               const float* att_src, const float* att_dst, const float* grad_a_dst,
                                qot_stream_t stream) {
     if (N < 0 || !rowptr_t) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!grad_out || !a_src || !a_dst || !escr || !delta || !col_t || !pos_t || !grad_z || !grad_a_src)
         return QOT_ERR_BADARG;
+    if (att_src && (!att_dst || !grad_a_dst)) return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
         gat_bwd_src_kernel<4, kC><<<grid_for(N, G::RPB), 256, 0, (hipStream_t)stream>>>(
             grad_out, a_src, a_dst, escr, delta, rowptr_t, col_t, pos_t, grad_z, grad_a_src, N,
-            neg_slope);
+            neg_slope, att_src, att_dst, grad_a_dst);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// grad of att_src / att_dst ([heads*C] each) from z and the logit gradients; workspace: qot_gat_bn_partials_floats.
+extern "C" int qot_gat_att_grad(const float* z, const float* grad_a_src, const float* grad_a_dst, float* grad_att_src,
+                                float* grad_att_dst, float* workspace, int64_t N, int heads, int C, qot_stream_t stream) {
+    if (N < 0) return QOT_ERR_BADARG;
+    if (!grad_att_src || !grad_att_dst || !workspace) return QOT_ERR_BADARG;
+    if (N > 0 && (!z || !grad_a_src || !grad_a_dst)) return QOT_ERR_BADARG;
+    QOT_DISPATCH_GAT(heads, C, {
+        using G = GatCfg<4, kC>;
+        const int nblk = gat_blocks(N, G::RPB);
+        gat_att_grad_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(z, grad_a_src, grad_a_dst, workspace, N);
+        QOT_LAUNCH_CHECK();
+        gat_att_grad_final_kernel<<<grid_for(G::HC, 4), 256, 0, (hipStream_t)stream>>>(workspace, nblk, G::HC, grad_att_src, grad_att_dst);
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

@@ -736,6 +736,20 @@ extern "C" int qot_bn_stats(const float* x, int64_t N, int C, float eps, float m
     return QOT_OK;
 }
 
+// Batch statistics from per-workgroup column partials [nblk][2][C] of (x - shift), (x - shift)^2 produced by the
+// kernel that wrote x (qot_gat_fwd with bn_partials): mean / rstd / running statistics as qot_bn_stats, without
+// another pass over x.
+extern "C" int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t N, int C,
+                                          float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                          float* running_var, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N <= 0 || C <= 0 || nblk <= 0 || !shift || !partials || !mean || !rstd) return QOT_ERR_BADARG;
+    bn_finalize_stats_kernel<<<grid_for(C, 4), 256, 0, stream>>>(shift, partials, nblk, N, C, eps, momentum, mean, rstd,
+                                                                 running_mean, running_var);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
                             const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream) {
     if (N < 0) return QOT_ERR_BADARG;

@@ -648,26 +648,41 @@ class HeadFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------ GATConv (a7)
 class GatFn(torch.autograd.Function):
-    """Fused GAT edge softmax + aggregation (+bias).  ``graph`` carries the self loops."""
+    """GATConv after the dense projection: attention logits from ``z`` (``a[n,h] = <z[n,h,:], att[h,:]>``), fused edge
+    softmax + aggregation (+bias).  ``graph`` carries the self loops.  ``bn_stats=True`` also returns the
+    per-workgroup column partials of the output that the BatchNorm behind it turns into its batch statistics
+    (``BnFn`` ``partials=``): one pass over ``[N, 4C]`` fewer per layer."""
 
     @staticmethod
-    def forward(ctx, z, a_src, a_dst, bias, graph: GraphIndex, neg_slope: float):
-        require_cuda(z, a_src, a_dst, bias)
-        z, a_src, a_dst, bias = _f32c(z), _f32c(a_src), _f32c(a_dst), _f32c(bias)
+    def forward(ctx, z, att_src, att_dst, bias, graph: GraphIndex, neg_slope: float, bn_stats: bool = False):
+        require_cuda(z, att_src, att_dst, bias)
+        z, bias = _f32c(z), _f32c(bias)
+        heads, C = att_src.shape[-2], att_src.shape[-1]
+        att_s, att_d = _f32c(att_src).reshape(-1), _f32c(att_dst).reshape(-1)
         N, HC = z.shape
-        heads = a_src.shape[1]
-        C = HC // heads
-        out = torch.empty(N, HC, dtype=torch.float32, device=z.device)
-        stats = torch.empty(N, heads, 2, dtype=torch.float32, device=z.device)
+        dev = z.device
+        a_src = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        _lib.call("qot_gat_logits", P(z), P(att_s), P(att_d), P(a_src), P(a_dst), N, heads, C)
+        out = torch.empty(N, HC, dtype=torch.float32, device=dev)
+        stats = torch.empty(N, heads, 2, dtype=torch.float32, device=dev)
+        partials = None
+        if bn_stats and N > 0:
+            partials = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
         _lib.call("qot_gat_fwd", P(z), P(a_src), P(a_dst), P(bias), P(graph.rowptr), P(graph.col), P(out),
-                  P(stats), N, heads, C, float(neg_slope))
-        ctx.save_for_backward(z, a_src, a_dst, stats)
-        ctx.graph, ctx.ns = graph, float(neg_slope)
+                  P(stats), N, heads, C, float(neg_slope), P(partials))
+        ctx.save_for_backward(z, a_src, a_dst, stats, att_s, att_d)
+        ctx.graph, ctx.ns, ctx.att_shape = graph, float(neg_slope), tuple(att_src.shape)
+        if bn_stats:
+            if partials is None:
+                partials = torch.empty(0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(partials)
+            return out, partials
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        z, a_src, a_dst, stats = ctx.saved_tensors
+    def backward(ctx, g, _gp=None):
+        z, a_src, a_dst, stats, att_s, att_d = ctx.saved_tensors
         graph, ns = ctx.graph, ctx.ns
         g = _f32c(g)
         N, HC = z.shape
@@ -681,9 +696,13 @@ class GatFn(torch.autograd.Function):
         delta = torch.empty(N, heads, dtype=torch.float32, device=dev)
         _lib.call("qot_gat_bwd_dst", P(g), P(z), P(a_src), P(a_dst), P(stats), P(graph.rowptr), P(graph.col),
                   P(gad), P(escr), P(delta), N, heads, C, ns)
+        # the source pass also sends the logit gradients back into grad_z through the attention vectors
         _lib.call("qot_gat_bwd_src", P(g), P(a_src), P(a_dst), P(escr), P(delta), P(graph.rowptr_t),
-                  P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns)
-        return gz, gas, gad, colsum(g), None, None
+                  P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns, P(att_s), P(att_d), P(gad))
+        g_att = torch.empty(2, HC, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
+        _lib.call("qot_gat_att_grad", P(z), P(gas), P(gad), _off(g_att, 0), _off(g_att, HC), P(ws), N, heads, C)
+        return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), colsum(g), None, None, None
 
 
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)
@@ -708,7 +727,10 @@ class BnFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, sync=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, sync=False,
+                partials=None):
+        """``partials = (column partials, shift)`` from the producer of ``x`` (``GatFn(bn_stats=True)``; shift = its
+        bias): the batch statistics come from them instead of a pass over ``x`` (single process, training mode)."""
         require_cuda(x, weight, bias)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         N, C = x.shape
@@ -741,9 +763,15 @@ class BnFn(torch.autograd.Function):
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {C}]")
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
-            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
-            _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),
-                      P(running_mean), P(running_var), P(part))
+            if partials is not None and partials[0].numel() > 0 and C % 4 == 0:
+                part, shift = partials
+                nblk = _lib.load().qot_gat_blocks(N, 4, C // 4)
+                _lib.call("qot_bn_stats_from_partials", P(_f32c(shift)), P(part), nblk, N, C, float(eps), float(momentum),
+                          P(mean), P(rstd), P(running_mean), P(running_var))
+            else:
+                part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+                _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),
+                          P(running_mean), P(running_var), P(part))
         else:
             mean = running_mean.detach().to(torch.float32).contiguous()
             rstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
@@ -780,7 +808,7 @@ class BnFn(torch.autograd.Function):
         if N > 0:
             _lib.call("qot_bn_bwd_apply", P(g), P(y), P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
                       N, C, int(relu), int(training))
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ LUT rows (a9)

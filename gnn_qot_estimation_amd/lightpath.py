@@ -61,8 +61,13 @@ class LightpathGNN(nn.Module):
         n = x.shape[0]
         graph = graph_index_for(data, n, gat_self_loops=True)
         for layer in range(1, self.num_layers + 1):
-            x = getattr(self, f"conv{layer}")(x, edge_index, graph=graph)
-            x = getattr(self, f"norm{layer}")(x, relu=True)        # BatchNorm + F.relu fused
+            conv = getattr(self, f"conv{layer}")
+            if self.training:      # the conv's epilogue leaves the BatchNorm's column partials behind
+                x, part = conv(x, edge_index, graph=graph, bn_stats=True)
+                x = getattr(self, f"norm{layer}")(x, relu=True, partials=(part, conv.bias))
+            else:
+                x = conv(x, edge_index, graph=graph)
+                x = getattr(self, f"norm{layer}")(x, relu=True)    # BatchNorm + F.relu fused
         idx = self._lut_rows(data)
         if idx.numel() == 0:          # only with allow_empty_lut: zero rows that still hang on the graph
             return x[:0, :self.mlp[3].out_features], batch[:0]

@@ -132,21 +132,20 @@ class GATConv(nn.Module):
             nn.init.uniform_(a, -stdv, stdv)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, graph: Optional[GraphIndex] = None):
-        n, h, c = x.shape[0], self.heads, self.out_channels
+    def forward(self, x, edge_index, graph: Optional[GraphIndex] = None, bn_stats: bool = False):
+        """``bn_stats=True`` (build extension): returns ``(out, partials)`` where ``partials`` are the column partials of
+        ``out - bias`` a following ``BatchNorm(..., partials=(partials, conv.bias))`` uses for its batch statistics."""
+        n = x.shape[0]
+        if self.heads != 4:
+            raise NotImplementedError("only the reference's GATConv(F, C, heads=4, concat=True) configuration")
         if graph is None:
             graph = build_graph_index(edge_index, n, gat_self_loops=True)
         if not graph.gat_self_loops:
             raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
         z = self.lin(x)
-        # attention logits: a[n,h] = sum_c z[n,h,c] att[h,c] = x[n,:] . (sum_c W[h,c,:] att[h,c]).
-        # Folding att into the projection weight turns two [N, heads*C] elementwise passes +
-        # reductions (and their autograd copies) into one skinny GEMM [N,F] x [F, 2*heads].
-        w3 = self.lin.weight.view(h, c, self.in_channels)
-        w_att = torch.cat([(w3 * self.att_src.view(h, c, 1)).sum(1), (w3 * self.att_dst.view(h, c, 1)).sum(1)], 0)
-        a = x @ w_att.t()                                # [N, 2*heads]
-        a_src, a_dst = a[:, :h].contiguous(), a[:, h:].contiguous()
-        return QF.GatFn.apply(z, a_src, a_dst, self.bias, graph, self.negative_slope)
+        # attention logits a[n,h] = <z[n,h,:], att[h,:]> are formed from z inside the operator (one pass over z each
+        # way); their gradient returns into grad_z in the source pass of the backward
+        return QF.GatFn.apply(z, self.att_src, self.att_dst, self.bias, graph, self.negative_slope, bn_stats)
 
 
 class BatchNorm(nn.Module):
@@ -161,12 +160,15 @@ class BatchNorm(nn.Module):
         # one process per GPU: statistics over the global batch, as in the single-process reference
         self.sync_stats = True
 
-    def forward(self, x, relu: bool = False):
+    def forward(self, x, relu: bool = False, partials=None):
+        """``partials``: ``(column partials, shift)`` handed over by the producer of ``x`` (``GATConv(bn_stats=True)``)."""
         m = self.module
         if self.training:
             m.num_batches_tracked.add_(1)
+        if partials is not None and not (self.training and QF._dist_world()[1] == 1):
+            partials = None
         return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
-                             m.momentum, m.eps, relu, self.sync_stats)
+                             m.momentum, m.eps, relu, self.sync_stats, partials)
 
 
 def global_mean_pool(x, batch, size: Optional[int] = None, data=None):

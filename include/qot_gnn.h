@@ -258,20 +258,35 @@ int qot_pool_bwd(const float* grad_out, const int32_t* ptr, const int32_t* batch
 
 /* ---- GATConv (concat heads) ---------------------------------------------------------
  * z[N, heads*C], a_src/a_dst[N, heads]; graph = CSR built with gat_self_loops.
- * out[N, heads*C] (+bias fused); stats[N, heads, 2]. */
+ * out[N, heads*C] (+bias fused); stats[N, heads, 2].
+ * qot_gat_logits: a_src[n,h] = <z[n,h,:], att_src[h,:]>, a_dst likewise (App. B.3), one pass over z.
+ * qot_gat_fwd, bn_partials != NULL: also writes per-workgroup column sums of (out - bias) and (out - bias)^2,
+ *   [qot_gat_blocks(N, heads, C)][2][heads*C] floats (buffer of qot_gat_bn_partials_floats), which
+ *   qot_bn_stats_from_partials(shift = bias, ...) turns into the batch statistics of the BatchNorm that follows
+ *   (lightpath_training/models.py:30-31) without another pass over out. */
+int qot_gat_blocks(int64_t N, int heads, int C);
+size_t qot_gat_bn_partials_floats(int64_t N, int heads, int C);
+int qot_gat_logits(const float* z, const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                   int64_t N, int heads, int C, qot_stream_t stream);
 int qot_gat_fwd(const float* z, const float* a_src, const float* a_dst, const float* bias,
                 const int32_t* rowptr, const int32_t* col, float* out, float* stats, int64_t N,
-                int heads, int C, float neg_slope, qot_stream_t stream);
+                int heads, int C, float neg_slope, float* bn_partials, qot_stream_t stream);
 /* destination pass: grad_a_dst[N,heads], escr[cap, heads, 2] = (alpha, dalpha), delta[N,heads] */
 int qot_gat_bwd_dst(const float* grad_out, const float* z, const float* a_src, const float* a_dst,
                     const float* stats, const int32_t* rowptr, const int32_t* col, float* grad_a_dst,
                     float* escr, float* delta, int64_t N, int heads, int C, float neg_slope,
                     qot_stream_t stream);
-/* source pass: grad_z[N, heads*C], grad_a_src[N, heads] */
+/* source pass: grad_z[N, heads*C], grad_a_src[N, heads].  att_src != NULL (logits formed by qot_gat_logits):
+ * grad_z also receives grad_a_src[j,h] att_src[h,:] + grad_a_dst[j,h] att_dst[h,:]. */
 int qot_gat_bwd_src(const float* grad_out, const float* a_src, const float* a_dst, const float* escr,
                     const float* delta, const int32_t* rowptr_t, const int32_t* col_t,
                     const int32_t* pos_t, float* grad_z, float* grad_a_src, int64_t N, int heads,
-                    int C, float neg_slope, qot_stream_t stream);
+                    int C, float neg_slope, const float* att_src, const float* att_dst,
+                    const float* grad_a_dst, qot_stream_t stream);
+/* grad_att_src[h*C + c] = sum_n grad_a_src[n,h] z[n,h,c] (grad_att_dst with grad_a_dst); fixed summation order.
+ * workspace: qot_gat_bn_partials_floats(N, heads, C) floats. */
+int qot_gat_att_grad(const float* z, const float* grad_a_src, const float* grad_a_dst, float* grad_att_src,
+                     float* grad_att_dst, float* workspace, int64_t N, int heads, int C, qot_stream_t stream);
 
 /* ---- BatchNorm1d (+ fused ReLU) over the node matrix [N, C] -------------------------
  * qot_bn_stats: mean[C], rstd[C] (biased var, eps), and when running_* != NULL the
@@ -282,6 +297,11 @@ int qot_bn_stats(const float* x, int64_t N, int C, float eps, float momentum, fl
                  float* rstd, float* running_mean, float* running_var, float* partials,
                  qot_stream_t stream);
 /* y = relu?((x - mean) * rstd * w + b) */
+/* batch statistics from column partials [nblk][2][C] of (x - shift), (x - shift)^2 written by the producer of x
+ * (qot_gat_fwd): same results as qot_bn_stats without reading x again. */
+int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t N, int C, float eps,
+                               float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                               qot_stream_t stream);
 int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
                  const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream);
 /* train-mode backward: needs column sums first (qot_bn_bwd_reduce -> gw[C], gb[C]), then
