@@ -79,8 +79,8 @@ SIGNATURES = {
     "qot_bn_partials_floats": (_sz, [_i64, _int]),
     "qot_bn_stats": (_int, [_p, _i64, _int, _f, _f, _p, _p, _p, _p, _p, _p]),
     "qot_bn_apply": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
-    "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p]),
-    "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p]),
+    "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p, _p, _p]),
+    "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p, _p]),
     "qot_sgd_momentum": (_int, [_p, _p, _p, _i64, _f, _f, _int, _p]),
     "qot_sgd_momentum_multi": (_int, [_p, _p, _p, _int, _p, _p, _i64, _f, _p, _f, _int, _p]),
     "qot_sgd_momentum_dev": (_int, [_p, _p, _p, _i64, _p, _f, _int, _p]),

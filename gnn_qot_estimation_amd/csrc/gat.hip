@@ -8,6 +8,7 @@
 // Mapping: TPR = min(64, HC/4) lanes per destination, NV = HC/(4*TPR) float4 per lane;
 // float4 number v of lane `sub` covers channels 4*(sub + TPR*v) .. +3, all in one head.
 #include "common.hpp"
+#include "mfma_tile.hpp"      // num_cus()
 
 namespace qot {
 
@@ -79,32 +80,34 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
             acc[v] = f4zero();
         }
         const int beg = rowptr[i], end = rowptr[i + 1];
-        for (int p = beg; p < end; p += 2) {
-            const bool two = p + 1 < end;
-            const int64_t j0 = col[p];
-            const int64_t j1 = two ? col[p + 1] : j0;
-            float4 z0[G::NV], z1[G::NV];
-            float as0[G::NV], as1[G::NV];
+        // EB in-edges in flight per lane group: two where a lane holds one float4 of the row, one where it already
+        // holds several (wide rows: the extra registers would cost resident waves)
+        constexpr int EB = (G::NV == 1) ? 2 : 1;
+        for (int p = beg; p < end; p += EB) {
+            int64_t jj[EB];
+            float4 zz[EB][G::NV];
+            float as_[EB][G::NV];
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) {
-                z0[v] = ld4(z + j0 * G::HC + 4 * (sub + G::TPR * v));
-                z1[v] = ld4(z + j1 * G::HC + 4 * (sub + G::TPR * v));
-                as0[v] = a_src[j0 * HEADS + hh[v]];
-                as1[v] = a_src[j1 * HEADS + hh[v]];
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (e == 1 && !two) break;
+            for (int e = 0; e < EB; ++e) {
+                jj[e] = col[(p + e < end) ? p + e : p];
 #pragma unroll
                 for (int v = 0; v < G::NV; ++v) {
-                    const float4 zj = e ? z1[v] : z0[v];
-                    const float raw = (e ? as1[v] : as0[v]) + ad[v];
+                    zz[e][v] = ld4(z + jj[e] * G::HC + 4 * (sub + G::TPR * v));
+                    as_[e][v] = a_src[jj[e] * HEADS + hh[v]];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                if (e > 0 && p + e >= end) break;
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    const float raw = as_[e][v] + ad[v];
                     const float s = raw > 0.f ? raw : ns * raw;
                     const float mn = fmaxf(m[v], s);
                     const float sc = __expf(m[v] - mn);
                     const float pe = __expf(s - mn);
                     l[v] = fmaf(l[v], sc, pe);
-                    acc[v] = fma4(pe, zj, scale4(sc, acc[v]));
+                    acc[v] = fma4(pe, zz[e][v], scale4(sc, acc[v]));
                     m[v] = mn;
                 }
             }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
 
 // source pass over the CSC: grad_z_j = sum_{e: j->i} alpha_e g_i ; grad_a_src[j,h] = sum_e ds_e.
 template <int HEADS, int C>
-__global__ __launch_bounds__(256) void gat_bwd_src_kernel(
+__global__ __launch_bounds__(256, 8) void gat_bwd_src_kernel(
     const float* __restrict__ g, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
@@ -322,9 +325,20 @@ using namespace qot;
         default: return QOT_ERR_UNSUPPORTED;                               \
     }
 
-static int gat_blocks(int64_t N, int rpb) {
-    int64_t b = (N + rpb - 1) / rpb;
-    const int64_t cap = 2048;          // >= 8 workgroups per CU; each folds its rows' BatchNorm partials
+// Workgroups of the chunked kernels (forward, att gradient) = rows of their partials buffers: ONE resident round
+// (what the occupancy of the forward kernel admits per CU x CUs; a second, partly filled round cost 30 %), at most 2048.
+template <int C>
+static int gat_blocks_for(int64_t N) {
+    using G = GatCfg<4, C>;
+    static int per_cu = 0;
+    if (!per_cu) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gat_fwd_kernel<4, C>, 256, 0) != hipSuccess || occ <= 0) occ = 4;
+        per_cu = occ > 8 ? 8 : occ;
+    }
+    int64_t b = (N + G::RPB - 1) / G::RPB;
+    int64_t cap = (int64_t)per_cu * num_cus();
+    if (cap > 2048) cap = 2048;
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
@@ -334,10 +348,8 @@ extern "C" size_t qot_gat_bn_partials_floats(int64_t N, int heads, int C) {
 
 // number of workgroups qot_gat_fwd / qot_gat_att_grad launch = rows of their partials buffers
 extern "C" int qot_gat_blocks(int64_t N, int heads, int C) {
-    if (heads != 4 || C <= 0) return 0;
-    const int hc4 = heads * C / 4;
-    const int tpr = hc4 < 64 ? hc4 : 64;
-    return gat_blocks(N, 256 / tpr);
+    QOT_DISPATCH_GAT(heads, C, { return gat_blocks_for<kC>(N); });
+    return 0;
 }
 
 extern "C" int qot_gat_logits(const float* z, const float* att_src, const float* att_dst, float* a_src, float* a_dst,
@@ -362,7 +374,7 @@ extern "C" int qot_gat_fwd(const float* z, const float* a_src, const float* a_ds
     if (!z || !a_src || !a_dst || !bias || !col || !out || !stats) return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        const int nblk = gat_blocks(N, G::RPB);
+        const int nblk = gat_blocks_for<kC>(N);
         gat_fwd_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(
             z, a_src, a_dst, bias, rowptr, col, out, stats, N, neg_slope, bn_partials);
     });
@@ -416,7 +428,7 @@ extern "C" int qot_gat_att_grad(const float* z, const float* grad_a_src, const f
     if (N > 0 && (!z || !grad_a_src || !grad_a_dst)) return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        const int nblk = gat_blocks(N, G::RPB);
+        const int nblk = gat_blocks_for<kC>(N);
         gat_att_grad_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(z, grad_a_src, grad_a_dst, workspace, N);
         QOT_LAUNCH_CHECK();
         gat_att_grad_final_kernel<<<grid_for(G::HC, 4), 256, 0, (hipStream_t)stream>>>(workspace, nblk, G::HC, grad_att_src, grad_att_dst);

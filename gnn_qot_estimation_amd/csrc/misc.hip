@@ -151,7 +151,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partials,
-    int64_t N, int C, int relu) {
+    int64_t N, int C, int relu, const float* __restrict__ wgt, const float* __restrict__ bia) {
+    // relu with y == NULL: the mask is recomputed from x with the forward's own expression (bn_apply_kernel) -- one
+    // [N, C] read fewer than taking it from the saved output
     __shared__ float4 r1[256];
     __shared__ float4 r2[256];
     const int C4 = C / 4;
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
     float4 s1 = f4zero(), s2 = f4zero();
     if (slot < RPB) {
         const int c = 4 * sub;
-        float4 sh, mu, rs;
+        float4 sh, mu, rs, wv = f4zero(), bv = f4zero();
         if (MODE == 0) sh = ld4(x + c);
-        else { mu = ld4(mean + c); rs = ld4(rstd + c); }
+        else { mu = ld4(mean + c); rs = ld4(rstd + c); if (relu && !y) { wv = ld4(wgt + c); bv = ld4(bia + c); } }
         for (int64_t r = r0 + slot; r < r1e; r += RPB) {
             float4 xv = ld4(x + r * C + c);
             if (MODE == 0) {
@@ -176,11 +178,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
                 s2 = make_float4(fmaf(d.x, d.x, s2.x), fmaf(d.y, d.y, s2.y), fmaf(d.z, d.z, s2.z), fmaf(d.w, d.w, s2.w));
             } else {
                 float4 g = ld4(dy + r * C + c);
+                float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z, (xv.w - mu.w) * rs.w);
                 if (relu) {
-                    float4 yv = ld4(y + r * C + c);
+                    float4 yv = y ? ld4(y + r * C + c)
+                                  : make_float4(fmaf(xh.x, wv.x, bv.x), fmaf(xh.y, wv.y, bv.y), fmaf(xh.z, wv.z, bv.z), fmaf(xh.w, wv.w, bv.w));
                     g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
                 }
-                float4 xh = make_float4((xv.x - mu.x) * rs.x, (xv.y - mu.y) * rs.y, (xv.z - mu.z) * rs.z, (xv.w - mu.w) * rs.w);
                 s1 = add4(s1, g);
                 s2 = make_float4(fmaf(g.x, xh.x, s2.x), fmaf(g.y, xh.y, s2.y), fmaf(g.z, xh.z, s2.z), fmaf(g.w, xh.w, s2.w));
             }
@@ -266,19 +269,28 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ w,
                                     const float* __restrict__ gw, const float* __restrict__ gb,
-                                    float* __restrict__ gx, int64_t N, int C4, int relu, int batch_stats) {
+                                    float* __restrict__ gx, int64_t N, int C4, int relu, int batch_stats,
+                                    const float* __restrict__ bia) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= N * C4) return;
     int c = (int)(t % C4) * 4;
     float4 g = ld4(dy + 4 * t);
+    float4 rs = ld4(rstd + c), wv = ld4(w + c);
+    float4 xv = f4zero(), mu = f4zero();
+    if (batch_stats || (relu && !y)) { xv = ld4(x + 4 * t); mu = ld4(mean + c); }
     if (relu) {
-        float4 yv = ld4(y + 4 * t);
+        float4 yv;
+        if (y) yv = ld4(y + 4 * t);
+        else {      // the forward's own expression (bn_apply_kernel): same mask, one [N, C] read fewer
+            const float4 bv = ld4(bia + c);
+            yv = make_float4(fmaf((xv.x - mu.x) * rs.x, wv.x, bv.x), fmaf((xv.y - mu.y) * rs.y, wv.y, bv.y),
+                             fmaf((xv.z - mu.z) * rs.z, wv.z, bv.z), fmaf((xv.w - mu.w) * rs.w, wv.w, bv.w));
+        }
         g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
     }
-    float4 rs = ld4(rstd + c), wv = ld4(w + c);
     float4 o;
     if (batch_stats) {
-        float4 xv = ld4(x + 4 * t), mu = ld4(mean + c), a = ld4(gw + c), b = ld4(gb + c);
+        float4 a = ld4(gw + c), b = ld4(gb + c);
         const float in = 1.0f / (float)N;
         o.x = wv.x * rs.x * (g.x - b.x * in - (xv.x - mu.x) * rs.x * a.x * in);
         o.y = wv.y * rs.y * (g.y - b.y * in - (xv.y - mu.y) * rs.y * a.y * in);
@@ -729,7 +741,7 @@ extern "C" int qot_bn_stats(const float* x, int64_t N, int C, float eps, float m
     if (!x || !mean || !rstd || !partials || ((running_mean == nullptr) != (running_var == nullptr)))
         return QOT_ERR_BADARG;
     int nblk = bn_blocks(N);
-    bn_partial_kernel<0><<<nblk, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, nullptr, partials, N, C, 0);
+    bn_partial_kernel<0><<<nblk, 256, 0, stream>>>(x, nullptr, nullptr, nullptr, nullptr, partials, N, C, 0, nullptr, nullptr);
     QOT_LAUNCH_CHECK();
     bn_finalize_stats_kernel<<<grid_for(C, 4), 256, 0, stream>>>(x, partials, nblk, N, C, eps, momentum, mean, rstd, running_mean, running_var);
     QOT_LAUNCH_CHECK();
@@ -763,13 +775,13 @@ extern "C" int qot_bn_apply(const float* x, const float* mean, const float* rstd
 
 extern "C" int qot_bn_bwd_reduce(const float* grad_y, const float* y, const float* x, const float* mean,
                                  const float* rstd, float* gw, float* gb, int64_t N, int C, int relu,
-                                 float* partials, qot_stream_t stream_) {
+                                 float* partials, const float* w, const float* b, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N <= 0) return QOT_ERR_BADARG;
     if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
-    if (!grad_y || !x || !mean || !rstd || !gw || !gb || !partials || (relu && !y)) return QOT_ERR_BADARG;
+    if (!grad_y || !x || !mean || !rstd || !gw || !gb || !partials || (relu && !y && (!w || !b))) return QOT_ERR_BADARG;
     int nblk = bn_blocks(N);
-    bn_partial_kernel<1><<<nblk, 256, 0, stream>>>(x, grad_y, y, mean, rstd, partials, N, C, relu);
+    bn_partial_kernel<1><<<nblk, 256, 0, stream>>>(x, grad_y, y, mean, rstd, partials, N, C, relu, w, b);
     QOT_LAUNCH_CHECK();
     bn_finalize_bwd_kernel<<<grid_for(C, 4), 256, 0, stream>>>(partials, nblk, C, gw, gb);
     QOT_LAUNCH_CHECK();
@@ -779,14 +791,14 @@ extern "C" int qot_bn_bwd_reduce(const float* grad_y, const float* y, const floa
 extern "C" int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const float* mean,
                                 const float* rstd, const float* w, const float* gw, const float* gb,
                                 float* grad_x, int64_t N, int C, int relu, int batch_stats,
-                                qot_stream_t stream) {
+                                const float* b, qot_stream_t stream) {
     if (N < 0) return QOT_ERR_BADARG;
     if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
     if (N == 0) return QOT_OK;
-    if (!grad_y || !rstd || !w || !grad_x || (relu && !y)) return QOT_ERR_BADARG;
+    if (!grad_y || !rstd || !w || !grad_x || (relu && !y && (!b || !x || !mean))) return QOT_ERR_BADARG;
     if (batch_stats && (!x || !mean || !gw || !gb)) return QOT_ERR_BADARG;
     bn_bwd_apply_kernel<<<grid_for(N * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(
-        grad_y, y, x, mean, rstd, w, gw, gb, grad_x, N, C / 4, relu, batch_stats);
+        grad_y, y, x, mean, rstd, w, gw, gb, grad_x, N, C / 4, relu, batch_stats, b);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

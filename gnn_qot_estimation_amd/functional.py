@@ -147,6 +147,9 @@ class SmallLinearFn(torch.autograd.Function):
         m, k = x.shape
         n = weight.shape[0]
         ctx.save_for_backward(x, weight)
+        ctx.big = m * n * k >= (1 << 28)        # e.g. 65 536 LUT rows x 512 x 128: a real GEMM, the library's job
+        if ctx.big:
+            return torch.addmm(bias, x, weight.t())
         return _small_gemm(x, weight, bias, m, n, k, k, 1, 1, k)           # B(k,n) = W[n,k]
 
     @staticmethod
@@ -155,6 +158,8 @@ class SmallLinearFn(torch.autograd.Function):
         g = _f32c(g)
         m, k = x.shape
         n = weight.shape[0]
+        if ctx.big:
+            return (g @ weight if ctx.needs_input_grad[0] else None), g.t() @ x, colsum(g)
         gx = _small_gemm(g, weight, None, m, k, n, n, 1, k, 1) if ctx.needs_input_grad[0] else None   # g @ W
         gw = _small_gemm(g, x, None, n, k, m, 1, n, k, 1)                  # g^T @ x: A(i,r) = g[r,i]
         return gx, gw, colsum(g) if m >= 64 else g.sum(0)
@@ -778,13 +783,14 @@ class BnFn(torch.autograd.Function):
         y = torch.empty_like(x)
         if N > 0:
             _lib.call("qot_bn_apply", P(x), P(mean), P(rstd), P(weight), P(bias), P(y), N, C, int(relu))
-        ctx.save_for_backward(x, y, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0))
+        # the output is NOT kept for backward: the ReLU mask is recomputed from x (same expression, same bits)
+        ctx.save_for_backward(x, bias, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0))
         ctx.cfg = (bool(training), bool(relu), world > 1)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, mean, rstd, weight, n_tot = ctx.saved_tensors
+        x, bias, mean, rstd, weight, n_tot = ctx.saved_tensors
         training, relu, synced = ctx.cfg
         g = _f32c(g)
         N, C = x.shape
@@ -794,8 +800,8 @@ class BnFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         if N > 0:
             part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
-            _lib.call("qot_bn_bwd_reduce", P(g), P(y), P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
-                      P(part))
+            _lib.call("qot_bn_bwd_reduce", P(g), None, P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
+                      P(part), P(weight), P(bias))
         gw_use, gb_use = gw, gb
         if synced:
             dist, _ = _dist_world()
@@ -806,8 +812,8 @@ class BnFn(torch.autograd.Function):
             gw_use = (tot[:C] * scale).float().contiguous()
             gb_use = (tot[C:] * scale).float().contiguous()
         if N > 0:
-            _lib.call("qot_bn_bwd_apply", P(g), P(y), P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
-                      N, C, int(relu), int(training))
+            _lib.call("qot_bn_bwd_apply", P(g), None, P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
+                      N, C, int(relu), int(training), P(bias))
         return gx, gw, gb, None, None, None, None, None, None, None, None
 
 

@@ -305,13 +305,15 @@ int qot_bn_stats_from_partials(const float* shift, const float* partials, int nb
 int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
                  const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream);
 /* train-mode backward: needs column sums first (qot_bn_bwd_reduce -> gw[C], gb[C]), then
- * qot_bn_bwd_apply.  eval mode (batch_stats == 0) skips the mean-subtraction terms. */
+ * qot_bn_bwd_apply.  eval mode (batch_stats == 0) skips the mean-subtraction terms.
+ * relu != 0 with y == NULL: the ReLU mask is recomputed from x, mean, rstd, w (weight), b (bias) with the forward's
+ * expression instead of being read from the saved output -- one [N, C] read fewer in each kernel. */
 int qot_bn_bwd_reduce(const float* grad_y, const float* y, const float* x, const float* mean,
                       const float* rstd, float* gw, float* gb, int64_t N, int C, int relu,
-                      float* partials, qot_stream_t stream);
+                      float* partials, const float* w, const float* b, qot_stream_t stream);
 int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const float* mean,
                      const float* rstd, const float* w, const float* gw, const float* gb,
-                     float* grad_x, int64_t N, int C, int relu, int batch_stats,
+                     float* grad_x, int64_t N, int C, int relu, int batch_stats, const float* b,
                      qot_stream_t stream);
 
 /* ---- train-step envelope helpers (topological_training/train.py:109-116) ----------------
