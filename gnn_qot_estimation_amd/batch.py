@@ -104,11 +104,55 @@ class Batch(Data):
         return out
 
 
-def shard_graphs(batch: Batch, rank: int, world: int) -> Batch:
-    """Contiguous graph range of ``batch`` for ``rank`` (data-parallel split)."""
+def balanced_ranges(weights, world: int):
+    """``world`` contiguous ranges ``[lo, hi)`` over ``len(weights)`` items whose weight sums are as even as contiguity
+    allows: boundary k is the first prefix reaching ``k/world`` of the total.  Deterministic, every rank computes the
+    same cuts from the same counts; a range may be empty."""
+    w = torch.as_tensor(weights, dtype=torch.float64).reshape(-1).cpu()
+    n = w.numel()
+    if n == 0:
+        return [(0, 0)] * world
+    csum = torch.cumsum(w, 0)
+    total = float(csum[-1])
+    if total <= 0:
+        return [((n * r) // world, (n * (r + 1)) // world) for r in range(world)]
+    # cut k sits where the running sum is closest to k/world of the total (between items)
+    targets = torch.arange(1, world, dtype=torch.float64) * (total / world)
+    right = torch.searchsorted(csum, targets, right=False)              # first prefix >= target
+    cuts = []
+    for t, i in zip(targets.tolist(), right.tolist()):
+        below = float(csum[i - 1]) if i > 0 else 0.0
+        cuts.append(i + 1 if (float(csum[i]) - t) <= (t - below) else i)  # include item i when that lands closer
+    cuts = [0] + [min(max(c, 0), n) for c in cuts] + [n]
+    for k in range(1, len(cuts)):
+        cuts[k] = max(cuts[k], cuts[k - 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def graph_costs(batch: "Batch", mode: str = "edges"):
+    """Per-graph cost for sharding: ``"edges"`` = directed edge count ("balanced by sum e"), ``"work"`` =
+    edges + nodes (every kernel on the path walks one or the other)."""
+    ep = getattr(batch, "edge_ptr", None)
+    nodes = (batch.ptr[1:] - batch.ptr[:-1]).to(torch.float64).cpu()
+    if ep is None:
+        return nodes
+    edges = (ep[1:] - ep[:-1]).to(torch.float64).cpu()
+    return edges if mode == "edges" else edges + nodes
+
+
+def shard_graphs(batch: Batch, rank: int, world: int, balance: str = "graphs") -> Batch:
+    """Contiguous graph range of ``batch`` for ``rank`` (data-parallel split).  ``balance="edges"``
+    cuts the ranges by per-graph work (edges + nodes) instead of graph count: skewed batches (power-law
+    topologies, BASELINE configs[4]) then give every rank the same amount of gather work; losses are weighted by
+    row counts (``dp.loss_scale``), so uneven graph counts per rank do not change the result."""
     b = batch.num_graphs
-    lo = (b * rank) // world
-    hi = (b * (rank + 1)) // world
+    if balance in ("edges", "work"):
+        lo, hi = balanced_ranges(graph_costs(batch, balance), world)[rank]
+    elif balance == "graphs":
+        lo = (b * rank) // world
+        hi = (b * (rank + 1)) // world
+    else:
+        raise ValueError("balance must be 'graphs', 'edges' or 'work'")
     ptr = batch.ptr
     n0, n1 = int(ptr[lo]), int(ptr[hi])
     out = Batch()

@@ -211,6 +211,10 @@ def loss_scale(n_local: int, device, group=None) -> torch.Tensor:
     return (t * dist.get_world_size(group) / tot.clamp_min(1.0)).float().reshape(())
 
 
-def graph_range(num_graphs: int, rank: int, world: int):
-    """Contiguous graph range [lo, hi) owned by ``rank``."""
+def graph_range(num_graphs: int, rank: int, world: int, costs=None):
+    """Contiguous graph range [lo, hi) owned by ``rank``: equal counts, or -- with per-graph ``costs`` (e.g. edges +
+    nodes) -- equal work (``batch.balanced_ranges``; SURVEY 8(e) "balanced by sum e")."""
+    if costs is not None:
+        from .batch import balanced_ranges
+        return balanced_ranges(costs, world)[rank]
     return (num_graphs * rank) // world, (num_graphs * (rank + 1)) // world

@@ -143,15 +143,24 @@ def _rank_world():
     return 0, 1
 
 
-def _local_batches(idx: Sequence[int], batch_size: int, rank: int, world: int) -> List[List[int]]:
+def _graph_costs(dataset, idx: Sequence[int]):
+    """Per-graph edge counts of ``idx`` when the dataset is a pre-tensorised shard (else None: split by count)."""
+    if isinstance(dataset, PackedGraphs) and len(idx):
+        e = (dataset.edge_ptr[1:] - dataset.edge_ptr[:-1])
+        return e[torch.as_tensor(list(idx), dtype=torch.long)].to(torch.float64)
+    return None
+
+
+def _local_batches(idx: Sequence[int], batch_size: int, rank: int, world: int, costs=None) -> List[List[int]]:
     """One entry per GLOBAL batch of ``batch_size`` graphs: this rank's contiguous share of it (possibly empty
     when a trailing batch holds fewer graphs than there are ranks).  Every rank gets the same number of
     entries, so every rank issues the same sequence of collectives, and a step is the single-process step
-    over the same global batch."""
+    over the same global batch.  ``costs`` (per-graph edge counts, aligned with ``idx``): the cut inside each global
+    batch evens out edges instead of graph counts."""
     out: List[List[int]] = []
     for b0 in range(0, len(idx), batch_size):
         n = min(batch_size, len(idx) - b0)
-        lo, hi = graph_range(n, rank, world)
+        lo, hi = graph_range(n, rank, world, costs=None if costs is None or world == 1 else costs[b0:b0 + n])
         out.append(list(idx[b0 + lo:b0 + hi]))
     return out
 
@@ -243,7 +252,7 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     # the chunks repeat every few epochs, so later visits do no graph preparation at all
     resident = isinstance(dataset, PackedGraphs) and dataset.device is not None
     loader = GraphLoader(dataset, batch_size, shuffle=False, device=device, cache_batches=resident,
-                         batches=_local_batches(indices, batch_size, rank, world))
+                         batches=_local_batches(indices, batch_size, rank, world, _graph_costs(dataset, indices)))
     stats = RegressionStats(out_dim, device)
     skipped = 0
     training = opt is not None
@@ -399,7 +408,7 @@ def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: s
     model.eval()
     rank, world = _rank_world()
     loader = GraphLoader(dataset, batch_size, shuffle=False, device=device,
-                         batches=_local_batches(idx, batch_size, rank, world))
+                         batches=_local_batches(idx, batch_size, rank, world, _graph_costs(dataset, idx)))
     kept, skipped = [], 0
     with torch.no_grad():
         for b, data in enumerate(loader):

@@ -166,3 +166,69 @@ def test_run_epoch_ranks_stay_in_step_and_match_single_process(world, n_idx, bs)
         # the per-rank loss sums weight every rank's local mean by its row count -> the global sum
         assert abs(got[r]["loss"] - one["avg_loss"]) < 1e-5 and abs(got[r]["ev"] - ev["avg_loss"]) < 1e-5
         assert abs(got[r]["r2"] - one["r2"]) < 1e-4
+
+
+# --------------------------------------------------------------------------- work-balanced sharding of skewed batches
+def _skewed_batch():
+    """One power-law graph (60 nodes, hubs) in front of twelve small ones: equal graph counts per rank would give
+    rank 0 almost all the edges."""
+    from gnn_qot_estimation_amd import synthetic as S
+    import gnn_qot_estimation_amd as q
+    big = S.topological_batch(5, 1, n=60)
+    parts = [q.Data(edge_index=big.edge_index, edge_attr=big.edge_attr, node_ids=big.node_ids, num_nodes=60, y=big.y)]
+    for g in range(12):
+        b = S.topological_batch(2, 1, n=12, e=22, first_graph=g)
+        parts.append(q.Data(edge_index=b.edge_index, edge_attr=b.edge_attr, node_ids=b.node_ids, num_nodes=12, y=b.y))
+    return q.Batch.from_data_list(parts)
+
+
+def _skew_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from gnn_qot_estimation_amd.batch import shard_graphs
+        from gnn_qot_estimation_amd.dp import FlatModel, loss_scale
+        from oracle import sparse as O
+        torch.manual_seed(0)
+        full = _skewed_batch()
+        model = O.TopologicalGNN(60, 8, 3, 4, dropout_p=0.0)
+        flat = FlatModel(model)
+        flat.broadcast_params()
+        shard = shard_graphs(full, rank, world, balance="edges")
+        flat.zero_grad()
+        y = shard.y.view(-1, 3)
+        loss = F.smooth_l1_loss(model(shard), y)
+        (loss * loss_scale(y.shape[0], torch.device("cpu"))).backward()     # shards hold different graph counts
+        flat.all_reduce_grads()
+        ret[rank] = dict(grad=flat.flat_grad.clone(), edges=shard.num_edges, graphs=shard.num_graphs)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_edge_balanced_two_rank_split_of_a_skewed_batch():
+    """SURVEY 8(e) 'balanced by sum e': the 2-rank split evens out the work within 10 % and the averaged gradient is
+    still the single-process gradient."""
+    from gnn_qot_estimation_amd.batch import balanced_ranges, graph_costs, shard_graphs
+    from gnn_qot_estimation_amd.dp import FlatModel, graph_range
+    from oracle import sparse as O
+    full = _skewed_batch()
+    costs = graph_costs(full)
+    (a0, a1), (b0, b1) = balanced_ranges(costs, 2)
+    wa, wb = float(costs[a0:a1].sum()), float(costs[b0:b1].sum())
+    assert a0 == 0 and a1 == b0 and b1 == 13 and abs(wa - wb) <= 0.10 * max(wa, wb)
+    assert graph_range(13, 1, 2, costs=costs) == (b0, b1)
+    by_count = [shard_graphs(full, r, 2).num_edges for r in range(2)]
+    assert max(by_count) > 2 * min(by_count)                 # what the count split would have done
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_skew_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        got = dict(ret)
+    assert got[0]["graphs"] + got[1]["graphs"] == 13 and got[0]["graphs"] != got[1]["graphs"]
+    assert abs(got[0]["edges"] - got[1]["edges"]) <= 0.10 * max(got[0]["edges"], got[1]["edges"])
+    torch.manual_seed(0)
+    model = O.TopologicalGNN(60, 8, 3, 4, dropout_p=0.0)
+    flat = FlatModel(model)
+    F.smooth_l1_loss(model(full), full.y.view(-1, 3)).backward()
+    for r in range(2):
+        assert torch.allclose(got[r]["grad"], flat.flat_grad, rtol=1e-4, atol=1e-7), (got[r]["grad"] - flat.flat_grad).abs().max()
