@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 P = _lib.ptr
 lib = _lib.load()
 lib.qot_debug_gen_variant.argtypes = [ctypes.c_int]
-base = S.topological_batch(4, min(B, 16), n=n, e=e)
+base = S.topological_batch(int(os.environ.get("ABLATE_CFG", "4")), min(B, 16), n=n, e=e)
 b = S.tile_batch(base, B // min(B, 16)).to(dev)
 N, D, K = b.num_nodes, 4, 8
 g = build_graph_index(b.edge_index, N)
