@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
 // ---------------------------------------------------------------------------------------------- weight gradient
 template <int H>
 struct DwW {
-    static constexpr int AC = 16;                                   // input channels of a slice
+    static constexpr int AC = H >= 32 ? 32 : 16;                    // input channels of a slice
     static constexpr int NAC = H / AC;
     static constexpr int OC = H >= 128 ? 128 : (H < 32 ? 32 : H);   // output columns of a slice (H = 16: padded)
     static constexpr int NOC = (H + OC - 1) / OC;
@@ -358,8 +358,13 @@ struct DwW {
     static constexpr int NSLICE = NAC * NOC;
 };
 
+// Two roles per workgroup (512 threads): waves 0-3 GATHER tile t+1 (operand slice + g rows) into one half of a
+// double-buffered LDS image while waves 4-7 MULTIPLY tile t out of the other half; one barrier per tile.  A gather
+// round costs about as much as the 320 MFMAs it feeds (index chain, edge MLP, broadcasts: a cost per edge, whatever
+// the channel count -- measured 677 us gather-only vs 793 us MFMA-only at H = 128), and with every wave doing both
+// in turn the two added up (1208 us); side by side on the same SIMDs the vector and the matrix pipe run together.
 template <int H, int D>
-__global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
+__global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ g, int ldg, const float* __restrict__ ea,
     const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eidx, const float* __restrict__ invdeg,
@@ -371,81 +376,114 @@ __global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
     constexpr int RB = ROWS / 32;
     static_assert(ROWS % 32 == 0, "K + 2 even");
     constexpr int NT = RB * OCB;                    // 32x32 accumulator tiles of the slice
-    constexpr int TPW = (NT + 3) / 4;               // per wave (tile t belongs to wave t % 4)
-    __shared__ __attribute__((aligned(16))) float Atile[32 * ROWS];
-    __shared__ __attribute__((aligned(16))) float Gt[32 * OC];
+    constexpr int TPW = (NT + 3) / 4;               // per consumer wave (tile t belongs to consumer wave t % 4)
+    __shared__ __attribute__((aligned(16))) float Atile[2][32 * ROWS];
+    __shared__ __attribute__((aligned(16))) float Gt[2][32 * OC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave < 4;
+    const int cw = wave & 3;                        // consumer wave index
     const int r31 = lane & 31, hi = lane >> 5;
-    const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
+    const int sub = threadIdx.x & 7, il = (threadIdx.x & 255) >> 3;
     const int slice = blockIdx.x % NSLICE, split = blockIdx.x / NSLICE;
     const int a0 = (slice % NAC) * AC, o0 = (slice / NAC) * OC;
     const int64_t ntiles = (N + 31) / 32;
 
+    // The two roles are two separate loops with the same barrier count, so that the consumers' 80 accumulator registers
+    // are not live in the producers' code (one loop with a role branch inside spilled 192 B/lane at 128 registers).
+    if (producer) {
+#ifdef QOT_DIAG
+        if (variant == 6) __builtin_amdgcn_s_setprio(2);
+#endif
+        auto fill = [&](int64_t tile, int buf) {
+            const int64_t tile0 = tile * 32;
+            const int64_t i = tile0 + il;
+            {
+                const bool ok = i < N;
+#pragma unroll
+                for (int q = 0; q < OC / 8; q += 4) {
+                    const int cc = o0 + (OC / 8) * sub + q;
+                    const float4 v = (ok && cc < H) ? ld4(g + i * ldg + cc) : f4zero();
+                    *reinterpret_cast<float4*>(&Gt[buf][il * OC + (OC / 8) * sub + q]) = v;
+                }
+            }
+            constexpr int CPL = AC / 8;
+            float acc[K + 1][CPL], root[CPL];
+#ifdef QOT_DIAG
+            if (variant == 1) {
+#pragma unroll
+                for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+                    for (int c_ = 0; c_ < CPL; ++c_) acc[kk][c_] = 1.f + kk;
+#pragma unroll
+                for (int c_ = 0; c_ < CPL; ++c_) root[c_] = 1.f;
+            } else
+#endif
+            gen_gather<D, CPL, false>(x, ldx, a0 + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, 0, 0x7fffffff, acc, root);
+#pragma unroll
+            for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+                for (int c_ = 0; c_ < CPL; ++c_) Atile[buf][il * ROWS + kk * AC + CPL * sub + c_] = acc[kk][c_];
+#pragma unroll
+            for (int c_ = 0; c_ < CPL; ++c_) Atile[buf][il * ROWS + (K + 1) * AC + CPL * sub + c_] = root[c_];
+        };
+        int64_t tile = split;
+        if (tile < ntiles) fill(tile, 0);
+        __syncthreads();
+        int buf = 0;
+#pragma unroll 1
+        for (; tile < ntiles; tile += nsplit, buf ^= 1) {
+            if (tile + nsplit < ntiles) fill(tile + nsplit, buf ^ 1);
+            __syncthreads();
+        }
+        return;
+    }
+#ifdef QOT_DIAG
+    if (variant == 5) __builtin_amdgcn_s_setprio(2);
+#endif
     f32x16 dw[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dw[t][r] = 0.f;
-    // tile tt = wave + 4t has column block tt % OCB = wave % OCB for every t (OCB divides 4): one B operand per step
+    // tile tt = cw + 4t has column block tt % OCB = cw % OCB for every t (OCB divides 4): one B operand per step
     static_assert(4 % OCB == 0, "column block per wave");
     int aoff[TPW];
-    const int boff = hi * OC + (wave % OCB) * 32 + r31;
+    const int boff = hi * OC + (cw % OCB) * 32 + r31;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tt = wave + 4 * t;
+        const int tt = cw + 4 * t;
         const int rb = (tt < NT) ? tt / OCB : 0;
         aoff[t] = hi * ROWS + rb * 32 + r31;
     }
+    __syncthreads();
+    int buf = 0;
 #pragma unroll 1
-    for (int64_t tile = split; tile < ntiles; tile += nsplit) {
-        const int64_t tile0 = tile * 32;
-        const int64_t i = tile0 + il;
-        // this thread's piece of the g tile (row il, columns o0 + (OC/8)*sub ...) goes straight to LDS: the previous
-        // tile's readers are behind the barrier that ended its iteration
+    for (int64_t tile = split; tile < ntiles; tile += nsplit, buf ^= 1) {
+#ifdef QOT_DIAG
+        if (variant != 3)
+#endif
         {
-            const bool ok = i < N;
+            // dW[(kk,a), o] += sum over the tile's nodes: A operand = the tile read transposed (node = k index)
+            const float* At = Atile[buf];
+            const float* Gb = Gt[buf];
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                float av[TPW];
+                const float bv = Gb[boff + 2 * s * OC];
 #pragma unroll
-            for (int q = 0; q < OC / 8; q += 4) {
-                const int cc = o0 + (OC / 8) * sub + q;
-                const float4 v = (ok && cc < H) ? ld4(g + i * ldg + cc) : f4zero();
-                *reinterpret_cast<float4*>(&Gt[il * OC + (OC / 8) * sub + q]) = v;
+                for (int t = 0; t < TPW; ++t) av[t] = At[aoff[t] + 2 * s * ROWS];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    if (cw + 4 * t < NT) dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, dw[t], 0, 0, 0);
             }
         }
-        float acc[K + 1][2], root[2];
-#ifdef QOT_DIAG
-        if (variant == 1) {
-#pragma unroll
-            for (int kk = 0; kk <= K; ++kk) { acc[kk][0] = 1.f + kk; acc[kk][1] = 2.f; }
-            root[0] = root[1] = 1.f;
-        } else
-#endif
-        gen_gather<D, 2, false>(x, ldx, a0 + 2 * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, 0, 0x7fffffff, acc, root);
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk)
-            *reinterpret_cast<float2*>(&Atile[il * ROWS + kk * AC + 2 * sub]) = make_float2(acc[kk][0], acc[kk][1]);
-        *reinterpret_cast<float2*>(&Atile[il * ROWS + (K + 1) * AC + 2 * sub]) = make_float2(root[0], root[1]);
         __syncthreads();
-#ifdef QOT_DIAG
-        if (variant == 3) { lds_barrier(); continue; }
-#endif
-        // dW[(kk,a), o] += sum over the tile's nodes: A operand = the tile read transposed (node = k index)
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            float av[TPW];
-            const float bv = Gt[boff + 2 * s * OC];
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) av[t] = Atile[aoff[t] + 2 * s * ROWS];
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                if (wave + 4 * t < NT) dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, dw[t], 0, 0, 0);
-        }
-        lds_barrier();
     }
     // slab[blockIdx][row (kk, a - a0)][o - o0]
     float* slab = slabs + (int64_t)blockIdx.x * ROWS * OC;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tt = wave + 4 * t;
+        const int tt = cw + 4 * t;
         if (tt < NT) {
             const int rb = tt / OCB, cb = tt % OCB;
 #pragma unroll
@@ -459,23 +497,33 @@ __global__ __launch_bounds__(256, (H >= 128 ? 2 : 3)) void nnconv_dw_gen_kernel(
 
 // sum over the node splits (fixed order), written straight into the parameters' layouts:
 //   dst = [ g(nn.2.weight)[a*H+o, k] (H*H*K) | g(nn.2.bias)[a*H+o] (H*H) | g(lin.weight)[o, a] (H*H) ]
-template <int H>
+// LANES lanes per output element stride over the splits and meet in a fixed butterfly (a serial loop over hundreds of
+// slabs per element is a chain of dependent-latency loads: 320 us at the reference's own H = 16 scale).
+template <int H, int LANES>
 __global__ void nnconv_dw_final_kernel(const float* __restrict__ slabs, int nsplit, int K, float* __restrict__ dst) {
     using W = DwW<H>;
-    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t e = t / LANES;
+    const int sub = (int)(t % LANES);
     const int64_t hh = (int64_t)H * H;
-    if (e >= hh * (K + 2)) return;
-    int kk, a, o;
-    if (e < hh * K) { kk = (int)(e % K); const int64_t ao = e / K; a = (int)(ao / H); o = (int)(ao % H); }
-    else if (e < hh * (K + 1)) { kk = K; const int64_t ao = e - hh * K; a = (int)(ao / H); o = (int)(ao % H); }
-    else { kk = K + 1; const int64_t oa = e - hh * (K + 1); o = (int)(oa / H); a = (int)(oa % H); }
-    const int slice = (a / W::AC) + W::NAC * (o / W::OC);
-    const int rows = (K + 2) * W::AC;
-    const int64_t off = ((int64_t)slice * rows + kk * W::AC + (a % W::AC)) * W::OC + (o % W::OC);
-    const int64_t stride = (int64_t)W::NSLICE * rows * W::OC;
+    const bool live = e < hh * (K + 2);
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slabs[sp * stride + off];
-    dst[e] = s;
+    if (live) {
+        int kk, a, o;
+        if (e < hh * K) { kk = (int)(e % K); const int64_t ao = e / K; a = (int)(ao / H); o = (int)(ao % H); }
+        else if (e < hh * (K + 1)) { kk = K; const int64_t ao = e - hh * K; a = (int)(ao / H); o = (int)(ao % H); }
+        else { kk = K + 1; const int64_t oa = e - hh * (K + 1); o = (int)(oa / H); a = (int)(oa % H); }
+        const int slice = (a / W::AC) + W::NAC * (o / W::OC);
+        const int rows = (K + 2) * W::AC;
+        const int64_t off = ((int64_t)slice * rows + kk * W::AC + (a % W::AC)) * W::OC + (o % W::OC);
+        const int64_t stride = (int64_t)W::NSLICE * rows * W::OC;
+        for (int sp = sub; sp < nsplit; sp += LANES) s += slabs[sp * stride + off];
+    }
+    if constexpr (LANES > 1) {
+#pragma unroll
+        for (int o2 = LANES / 2; o2 > 0; o2 >>= 1) s += __shfl_xor(s, o2);
+    }
+    if (live && sub == 0) dst[e] = s;
 }
 
 // ---------------------------------------------------------------------------------------------- grad of nn.0.*
@@ -713,8 +761,9 @@ int qot_nnconv_gen_launch(const float* x, int ld_x, const float* edge_attr, cons
 
 static int dw_splits(int64_t N, int nslice) {
     const int64_t ntiles = (N + 31) / 32;
-    int64_t s = (4 * (int64_t)num_cus() + nslice - 1) / nslice;      // ~4 workgroups per CU in all
-    if (s > ntiles) s = ntiles;
+    int64_t s = ((int64_t)num_cus() + nslice - 1) / nslice;          // one 8-wave workgroup per CU in all
+    const int64_t by_work = (ntiles + 7) / 8;                         // a workgroup's slab should stand for >= 8 tiles
+    if (s > by_work) s = by_work;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -734,7 +783,7 @@ static int dw_oc(int H) { return H >= 128 ? 128 : (H < 32 ? 32 : H); }
 extern "C" size_t qot_nnconv_dw_workspace_floats(int64_t N, int H, int D) {
     const int ns = dw_nslice(H);
     if (!ns || N <= 0) return 16;
-    return (size_t)dw_splits(N, ns) * ns * (size_t)((2 * D + 2) * 16) * dw_oc(H);
+    return (size_t)dw_splits(N, ns) * ns * (size_t)((2 * D + 2) * (H >= 32 ? 32 : 16)) * dw_oc(H);
 }
 
 // Weight gradient of NNConv for any supported width: grad_params = [g(nn.2.weight) | g(nn.2.bias) | g(lin.weight)]
@@ -756,11 +805,16 @@ extern "C" int qot_nnconv_dw(const float* x, int ld_x, const float* grad_out, in
     const int variant = 0;
 #endif
     QOT_DISPATCH_GEN_H(H, QOT_DISPATCH_D4(D, {
-        nnconv_dw_gen_kernel<kH, kD><<<nsplit * ns, 256, 0, stream>>>(x, ld_x, grad_out, ld_g, edge_attr, w1, b1, rowptr,
+        nnconv_dw_gen_kernel<kH, kD><<<nsplit * ns, 512, 0, stream>>>(x, ld_x, grad_out, ld_g, edge_attr, w1, b1, rowptr,
                                                                       col, eid, invdeg, workspace, N, nsplit, variant);
         QOT_LAUNCH_CHECK();
         const int64_t elems = (int64_t)(2 * kD + 2) * kH * kH;
-        nnconv_dw_final_kernel<kH><<<grid_for(elems, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);
+        if (nsplit >= 64)
+            nnconv_dw_final_kernel<kH, 16><<<grid_for(elems * 16, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);
+        else if (nsplit >= 8)
+            nnconv_dw_final_kernel<kH, 4><<<grid_for(elems * 4, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);
+        else
+            nnconv_dw_final_kernel<kH, 1><<<grid_for(elems, 256), 256, 0, stream>>>(workspace, nsplit, 2 * kD, grad_params);
     }));
     QOT_LAUNCH_CHECK();
     return QOT_OK;

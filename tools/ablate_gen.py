@@ -42,7 +42,7 @@ for rnd in range(4):
         lib.qot_debug_gen_variant(v); run(); res[v].append(t())
 lib.qot_debug_gen_variant(0)
 flops = 2.0 * N * (K + 2) * H * H
-names = {0: "full", 1: "no gather", 2: "no weight stream", 3: "gather only", 4: "LDS-fed MFMA only"}
+names = {0: "full", 1: "no gather", 2: "no weight stream", 3: "gather only", 4: "LDS-fed MFMA only", 5: "consumers prio 2", 6: "producers prio 2"}
 out_ = {"H": H, "N": N, "flops": flops}
 for v in range(5):
     us = min(res[v])
@@ -54,7 +54,7 @@ wsd = torch.empty(lib.qot_nnconv_dw_workspace_floats(N, H, D), device=dev)
 keep = run
 run = lambda: _lib.call("qot_nnconv_dw", P(x), H, P(gout), H, P(b.edge_attr), P(w1), P(b1), P(g.rowptr), P(g.col), P(g.eid),
                         P(g.invdeg), P(gpar), P(wsd), N, H, D)
-dres = {0: [], 1: [], 3: []}
+dres = {0: [], 1: [], 3: [], 5: [], 6: []}
 for rnd in range(3):
     for v in dres:
         lib.qot_debug_gen_variant(v); run(); dres[v].append(t())
