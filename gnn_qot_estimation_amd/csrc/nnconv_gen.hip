@@ -592,8 +592,30 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
                     f32x16 c;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c[r] = 0.f;
-#pragma unroll 4
-                    for (int gq = 0; gq < GH; ++gq) c = mfma_group(Gt4, gq, hi, r31, bp[gq * 64], c);
+                    // weight fragments of chunk ch+1 are requested before the MFMAs of chunk ch issue (loaded right in
+                    // front of their use, every group of 4 MFMAs waited for an L2 round trip)
+                    constexpr int GC = (GH % 4 == 0) ? 4 : 2;
+                    constexpr int NGC = GH / GC;
+                    float4 b0[GC], b1[GC];
+#pragma unroll
+                    for (int v = 0; v < GC; ++v) b0[v] = bp[v * 64];
+#pragma unroll 1
+                    for (int ch = 0; ch < NGC; ch += 2) {
+                        if (ch + 1 < NGC) {
+#pragma unroll
+                            for (int v = 0; v < GC; ++v) b1[v] = bp[((ch + 1) * GC + v) * 64];
+                        }
+#pragma unroll
+                        for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, ch * GC + v, hi, r31, b0[v], c);
+                        if (ch + 1 < NGC) {
+                            if (ch + 2 < NGC) {
+#pragma unroll
+                                for (int v = 0; v < GC; ++v) b0[v] = bp[((ch + 2) * GC + v) * 64];
+                            }
+#pragma unroll
+                            for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, (ch + 1) * GC + v, hi, r31, b1[v], c);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;

@@ -916,6 +916,11 @@ extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const flo
     if ((H != 16 && H != 32 && H != 64 && H != 128 && H != 256) || D > 4) return QOT_ERR_UNSUPPORTED;
     if (!grad_out || !x || !w1 || !b1 || !invdeg || !b_perm || !gw1 || !gb1 || !workspace || (ld_g & 3) || (ld_x & 3))
         return QOT_ERR_BADARG;
+#ifdef QOT_DIAG
+    if (H == 64 && g_variant == 9)       // A/B: the generic kernel at H = 64 (b_perm in ITS layout)
+        return qot_nnconv_gradh_gen_launch(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col, eid, invdeg, b_perm,
+                                           gw1, gb1, workspace, N, H, D, stream);
+#endif
     if (H != 64)     // other widths: GA built 32 input channels at a time (nnconv_gen.hip)
         return qot_nnconv_gradh_gen_launch(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col, eid, invdeg, b_perm,
                                            gw1, gb1, workspace, N, H, D, stream);
