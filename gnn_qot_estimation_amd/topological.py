@@ -49,10 +49,17 @@ class TopologicalGNN(nn.Module):
         """``(slope, p, seed, step)`` of the leaky_relu(0.01) + Dropout(p) that follows conv
         ``site`` (models.py:54-55 / 58-59); the conv kernels apply it in their epilogue."""
         p = self.dropout.p if self.training else 0.0
-        if self._qot_seed is None:
-            self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-        seed = (self._qot_seed + 0x9E3779B97F4A7C15 * (site + 1)) & 0xFFFFFFFFFFFFFFFF
+        seed = (self._seed() + 0x9E3779B97F4A7C15 * (site + 1)) & 0xFFFFFFFFFFFFFFFF
         return (0.01, p, seed, step if p > 0.0 else None)
+
+    def _seed(self) -> int:
+        """Base seed of the counter-based dropout draws: torch's seed, mixed with the data-parallel rank so that ranks
+        (which hold different graphs at the same element indices) do not draw identical masks."""
+        if self._qot_seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._qot_seed = (int(torch.initial_seed()) + 0xD1B54A32D192ED03 * rank) & 0x7FFFFFFFFFFFFFFF
+        return self._qot_seed
 
     def _check_node_ids(self, data, maps):
         """``nn.Embedding`` raises ``IndexError`` for an id outside ``[0, num_nodes)`` (models.py:12,52; the
@@ -121,9 +128,7 @@ class TopologicalGNN(nn.Module):
         if fused_head:
             # pool + head MLP (models.py:61-63) fused: one kernel forward, one backward
             p = self.mlp[2].p if self.training else 0.0
-            if self._qot_seed is None:
-                self._qot_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-            seed = (self._qot_seed + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
+            seed = (self._seed() + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
             act = (self.mlp[1].negative_slope, p, seed, step if p > 0.0 else None)
             ptr, B = batch_ptr_for(data, n)
             return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
