@@ -52,6 +52,7 @@ SIGNATURES = {
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
                                 _int, _f, _f, _u64, _p, _p]),
+    "qot_nnconv_bwd_finalize": (_int, [_p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_dw_workspace_floats": (_sz, [_i64, _int, _int]),
     "qot_nnconv_dw": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_gemm_tn_workspace_floats": (_sz, [_int]),

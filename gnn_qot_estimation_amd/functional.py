@@ -504,13 +504,14 @@ class NNConvFn(torch.autograd.Function):
         g = _f32c(g)
         if ctx.side is not None:
             # folded mode (decided at forward time): the consumer's backward (HeadFn) has gone back through this
-            # layer's activation and left the bias gradient here; ``g`` is wrt the PRE-activation output.  The entry
-            # is rewritten by every HeadFn.backward, so a second backward over a retained graph stays correct.
+            # layer's activation and left the bias gradient here; ``g`` is wrt the PRE-activation output.  Every
+            # HeadFn.backward leaves a fresh entry, so a second backward over a retained graph stays correct; it is
+            # popped (not read) so that autograd holds the only reference and assigns it as .grad without a copy kernel.
             if "gbias" not in ctx.side:
                 raise RuntimeError("NNConv output was folded into the fused read-out, but the read-out's backward "
                                    "has not run: the conv output must feed only the read-out head "
                                    "(set model._qot_fold_head = False for other graphs)")
-            gbias = ctx.side["gbias"]
+            gbias = ctx.side.pop("gbias")
         elif ctx.act is not None:
             g, gbias = act_backward_colsum(g, y, ctx.act + (act_step,))
         else:
@@ -520,34 +521,37 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         hh = hin * hout
+        gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
+        gb1 = torch.empty(K, dtype=torch.float32, device=dev)
+        wsh = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
+        gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
+        gradh_args = (P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col), P(graph.eid),
+                      P(graph.invdeg), P(bp))
         if hin == 64 and not os.environ.get("QOT_SPLIT_NNCONV_BWD"):
-            # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U
+            # one gather feeds both products: grad_x = U @ WcatT and gWcat = X^T U; the slab sum of the weight gradient
+            # and the block sum of the grad-h kernel share one launch behind both kernels
             gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
-            gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
-                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 1, P(ws), N, hin, D)
+                      P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 2, P(ws), N, hin, D)
+            _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
+            _lib.call("qot_nnconv_bwd_finalize", P(ws), P(wsh), P(gpar), P(gw1), P(gb1), N, hin, D)
         else:
             # grad_x: the forward kernel over the transposed graph with the per-block transposed weights;
-            # weight gradient: A^T g by slices of the result, the operand gathered 16 channels at a time
+            # weight gradient: A^T g by slices of the result, the operand gathered 32 channels at a time
             gx = None
             if ctx.needs_input_grad[0]:
                 gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
                 _lib.call("qot_nnconv_fused", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                           P(graph.col_t), P(graph.eid_t), P(graph.invdeg), 1, P(wp_adj), None, P(gx), N, hout, D,
                           0, 0.0, 0.0, 0, None)
-            gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_dw_workspace_floats(N, hin, D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_dw", P(x), hin, P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                       P(graph.eid), P(graph.invdeg), P(gpar), P(ws), N, hin, D)
+            # grad of the edge MLP's first layer
+            _lib.call("qot_nnconv_gradh_fused", *gradh_args, P(gw1), P(gb1), P(wsh), N, hin, D)
         # already in the parameters' own layouts (no permute / copy kernels)
         gw2, gb2, gwroot = gpar[:hh * K].view(hh, K), gpar[hh * K:hh * (K + 1)], gpar[hh * (K + 1):].view(hout, hin)
-        # grad of the edge MLP's first layer
-        gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
-        gb1 = torch.empty(K, dtype=torch.float32, device=dev)
-        ws = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
-        _lib.call("qot_nnconv_gradh_fused", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr),
-                  P(graph.col), P(graph.eid), P(graph.invdeg), P(bp), P(gw1), P(gb1), P(ws), N, hin, D)
         return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
 
 

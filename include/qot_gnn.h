@@ -232,6 +232,11 @@ int qot_nnconv_dw(const float* x, int ld_x, const float* grad_out, int ld_g, con
                   const float* w1, const float* b1, const int32_t* rowptr, const int32_t* col,
                   const int32_t* eid, const float* invdeg, float* grad_params, float* workspace, int64_t N,
                   int H, int D, qot_stream_t stream);
+/* H == 64: both second-stage sums of the NNConv backward in ONE launch.  Call qot_nnconv_adjoint_dw with
+ * param_layout = 2 (slabs stay in its workspace) and qot_nnconv_gradh_fused with gw1 = gb1 = NULL (block partials stay in
+ * its workspace), then this: grad_params as qot_nnconv_adjoint_dw(param_layout = 1), gw1[K,D], gb1[K].  Fixed order. */
+int qot_nnconv_bwd_finalize(const float* adj_workspace, const float* gradh_workspace, float* grad_params,
+                            float* gw1, float* gb1, int64_t N, int H, int D, qot_stream_t stream);
 /* grad of the edge MLP's first layer: GA[N, K*H] = g @ Wcat[:K*H]^T (caller GEMM);
  * gw1[K,D], gb1[K] zero-filled by caller, accumulated with atomics. */
 int qot_nnconv_bwd_edge(const float* GA, int ld_ga, const float* x, int ld_x,
