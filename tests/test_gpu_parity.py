@@ -788,3 +788,50 @@ def test_general_csr_build_capture_replay_equals_eager(cuda_device, gat):
             a, b = getattr(cap, n_), getattr(eager, n_)
             k = live if n_ in ("col", "eid", "row", "col_t", "pos_t", "eid_t") else a.numel()
             assert torch.equal(a[:k], b[:k]), (n_, gat)
+
+
+@pytest.mark.parametrize("H", [48, 20, 100])
+def test_topological_any_hidden_width_runs_zero_padded(cuda_device, H):
+    """The reference constructor takes any ``hidden_channels`` (models.py:7-9); widths without kernels of their own run
+    on the next supported width with zero-padded parameters (gnn_qot_estimation_amd/padded.py): same state_dict shapes,
+    forward and every gradient equal to the oracle at the TRUE width."""
+    from gnn_qot_estimation_amd import synthetic as S
+    batch = S.topological_batch(2, 5, n=24, e=60)
+    ref, hip = _models("topo", cuda_device, num_nodes=24, hidden_channels=H, out_channels=3, edge_dim=4, dropout_p=0.0,
+                       num_layers=3)
+    assert hip._qot_hp in (32, 64, 128)
+    ref.train(); hip.train()
+    out_ref = ref(batch)
+    out_hip = hip(batch.to(cuda_device))
+    assert rel_err(out_hip, out_ref) <= TOL
+    y = batch.y.view(-1, 3)
+    torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
+    torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip)
+    assert [tuple(v.shape) for v in hip.state_dict().values()] == [tuple(v.shape) for v in ref.state_dict().values()]
+
+
+@pytest.mark.parametrize("C,train", [(24, True), (24, False), (5, True)])
+def test_lightpath_any_hidden_width_runs_zero_padded(cuda_device, C, train):
+    from gnn_qot_estimation_amd import synthetic as S
+    batch = S.lightpath_batch(40)
+    ref, hip = _models("lp", cuda_device, in_channels=5, hidden_channels=C, output_dim=3, is_lut_index=1, dropout_p=0.0,
+                       num_layers=2)
+    with torch.no_grad():
+        for l in (1, 2):
+            for m in (getattr(ref, f"norm{l}").module, getattr(hip, f"norm{l}").module):
+                gen = torch.Generator().manual_seed(l)
+                m.running_mean.copy_(torch.rand(4 * C, generator=gen) - 0.5)
+                m.running_var.copy_(torch.rand(4 * C, generator=gen) + 0.5)
+    ref.train(train); hip.train(train)
+    o_r, b_r = ref(batch)
+    o_h, b_h = hip(batch.to(cuda_device))
+    assert torch.equal(b_h.cpu(), b_r) and rel_err(o_h, o_r) <= TOL
+    y = batch.y[b_r]
+    torch.nn.functional.smooth_l1_loss(o_r, y).backward()
+    torch.nn.functional.smooth_l1_loss(o_h, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip, analytic_zero=("conv1.bias", "conv2.bias") if train else ())
+    for l in (1, 2):
+        r, h = getattr(ref, f"norm{l}").module, getattr(hip, f"norm{l}").module
+        assert rel_err(h.running_mean, r.running_mean) <= TOL and rel_err(h.running_var, r.running_var) <= TOL
+        assert int(h.num_batches_tracked) == int(r.num_batches_tracked) == (1 if train else 0)
