@@ -835,3 +835,32 @@ def test_lightpath_any_hidden_width_runs_zero_padded(cuda_device, C, train):
         r, h = getattr(ref, f"norm{l}").module, getattr(hip, f"norm{l}").module
         assert rel_err(h.running_mean, r.running_mean) <= TOL and rel_err(h.running_var, r.running_var) <= TOL
         assert int(h.num_batches_tracked) == int(r.num_batches_tracked) == (1 if train else 0)
+
+
+@pytest.mark.parametrize("H,D,seed", [(16, 1, 0), (32, 3, 1), (64, 2, 2), (128, 3, 3), (256, 1, 4), (32, 4, 5), (128, 4, 6)])
+def test_topological_irregular_graphs_all_widths_and_edge_dims(cuda_device, H, D, seed):
+    """Random multigraphs per width / edge_dim: isolated nodes, duplicate edges, self loops, a hub, node counts that are
+    not a multiple of the 32-row tile, graphs of different sizes in one batch (per-node embedding path, not table mode),
+    3 layers -- forward and every gradient against the oracle."""
+    import gnn_qot_estimation_amd as q
+    g = torch.Generator().manual_seed(100 + seed)
+    datas = []
+    for n in (37, 5, 64, 1, 23):
+        e = int(torch.randint(0, 4 * n + 1, (1,), generator=g))
+        ei = torch.randint(0, n, (2, e), generator=g)
+        if n >= 20:
+            ei[1, : min(e, 19)] = 3                        # a hub destination
+            ei[:, -2:] = ei[:, :2]                         # duplicate edges
+        datas.append(q.Data(edge_index=ei, edge_attr=torch.rand(e, D, generator=g), y=torch.rand(3, generator=g),
+                            node_ids=torch.randperm(64, generator=g)[:n], num_nodes=n))
+    batch = q.Batch.from_data_list(datas)
+    ref, hip = _models("topo", cuda_device, num_nodes=64, hidden_channels=H, out_channels=3, edge_dim=D, dropout_p=0.0,
+                       num_layers=3)
+    ref.train(); hip.train()
+    out_ref = ref(batch)
+    out_hip = hip(batch.to(cuda_device))
+    assert rel_err(out_hip, out_ref) <= TOL
+    y = batch.y.view(-1, 3)
+    torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
+    torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip)
