@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void csr_by_graph_kernel(
         ptr32[b] = (int32_t)n0;
         if (b == B - 1) ptr32[B] = (int32_t)node_ptr[B];
     }
-    if (n > cap_n || m > cap_m || n < 0 || m < 0) {      // host-side size bound violated: flag, do nothing
+    // host-side size bound violated, or slices that do not lie inside the arrays: flag, write nothing
+    if (n > cap_n || m > cap_m || n < 0 || m < 0 || n0 < 0 || e0 < 0 || n0 + n > N || e0 + m > E) {
         if (threadIdx.x == 0 && status) atomicOr(status, 2);
         return;
     }

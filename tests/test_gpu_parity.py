@@ -489,15 +489,29 @@ def test_csr_by_graph_equals_general_build(cuda_device):
     st = torch.zeros(1, dtype=torch.int32, device=dev)
     bad = ei.clone(); bad[0, 0] = N - 1
     g = b
-    _lib.call("qot_csr_build_by_graph", P(bad), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), max(sizes),
+    # (named device tensors: a pointer taken from a temporary `ptr.to(dev)` outlives it, and the next temporary reuses
+    #  the block -- the kernel then saw edge_ptr in both arguments and wrote past the index arrays)
+    ptr_d, eptr_d = ptr.to(dev), eptr.to(dev)
+    _lib.call("qot_csr_build_by_graph", P(bad), ei.shape[1], N, P(ptr_d), P(eptr_d), len(sizes), max(sizes),
               max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
               P(g.invdeg), P(st), None, None, None, None, None)
     assert int(st.item()) & 1
     st.zero_()
-    _lib.call("qot_csr_build_by_graph", P(ei), ei.shape[1], N, P(ptr.to(dev)), P(eptr.to(dev)), len(sizes), 100,
+    _lib.call("qot_csr_build_by_graph", P(ei), ei.shape[1], N, P(ptr_d), P(eptr_d), len(sizes), 100,
               max(ecnt), P(g.rowptr), P(g.col), P(g.eid), P(g.row), P(g.rowptr_t), P(g.col_t), P(g.pos_t), P(g.eid_t),
               P(g.invdeg), P(st), None, None, None, None, None)
     assert int(st.item()) & 2
+    # slices that do not lie inside the arrays (here: the edge slices passed as node slices, so "graphs" reach node
+    # 1614 of 393) are flagged and written nowhere: sentinel tails behind every node-indexed array stay intact
+    st.zero_()
+    tail = 2048
+    big = {k: torch.full((N + 1 + tail,), -7, dtype=getattr(g, k).dtype, device=dev) for k in ("rowptr", "rowptr_t", "invdeg")}
+    _lib.call("qot_csr_build_by_graph", P(ei), ei.shape[1], N, P(eptr_d), P(eptr_d), len(sizes), 2048,
+              max(ecnt), P(big["rowptr"]), P(g.col), P(g.eid), P(g.row), P(big["rowptr_t"]), P(g.col_t), P(g.pos_t),
+              P(g.eid_t), P(big["invdeg"]), P(st), None, None, None, None, None)
+    assert int(st.item()) & 2
+    for k, v in big.items():
+        assert bool((v[N + 1:] == -7).all()), k
 
 
 @pytest.mark.gpu
