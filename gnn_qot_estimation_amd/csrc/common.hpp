@@ -63,6 +63,16 @@ __device__ __forceinline__ int group8_bcast(int v, bool upper) {
     return __builtin_bit_cast(int, group8_bcast<SRC>(__builtin_bit_cast(float, v), upper));
 }
 
+// Value of lane SRC (compile-time, 0..15) of every DPP row of 16 lanes, in all lanes of the row: ONE VALU move
+// (`row_newbcast:SRC`, gfx90a and later).  Written as __shfl(v, src, 16) with a runtime lane this is a
+// ds_bpermute_b32 + s_waitcnt lgkmcnt round trip through the LDS crossbar.
+template <int SRC>
+__device__ __forceinline__ float row16_bcast(float v) { return dpp_move<0x150 + SRC>(v); }
+template <int SRC>
+__device__ __forceinline__ int row16_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xF, 0xF, true);
+}
+
 // Sum over an aligned group of G consecutive lanes, result in every lane of the group.  Groups of up to 16
 // lanes stay inside a DPP row: quad_perm [1,0,3,2] and [2,3,0,1] pair lanes inside a quad, row_half_mirror
 // pairs the quads of an 8-lane half, row_mirror the two halves -- each step adds two partial sums of

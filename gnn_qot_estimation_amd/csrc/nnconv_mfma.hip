@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 // per workgroup and are summed in a fixed order afterwards (bitwise reproducible).
 constexpr int kAdjBlocksPerCu = 1;
 
-template <int D>
+// VARIANT (diagnostic build only): 0 production; 1 every gathered row read from ONE hot address (no row-load latency);
+// 2 no grad_x loop; 3 no weight-gradient loop; 4 no gather; 5 neither MFMA loop (gather + exchange only)
+template <int D, int VARIANT = 0>
 __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ xf, int ldx, const float* __restrict__ ea,
     const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr_t,
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
             xown = (j < N) ? ld4(xf + j * ldx + 4 * (threadIdx.x & 15)) : f4zero();
         }
         // ---- gather: 16 lanes per source node j (float4 = 64 channels), out-edges over the CSC
-        {
+        if (VARIANT != 4) {
             const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
             const int c0 = 4 * sub;
             const int64_t j = tile0 + il;
@@ -407,12 +409,12 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
                 if (p < end) {
-                    myi = col_t[p];
-                    const int64_t e = eid_t[p];
+                    myi = (VARIANT == 7) ? (int)(j ^ (p & 31)) : col_t[p];      // 7: no index chain (arithmetic ids)
+                    const int64_t e = (VARIANT == 7) ? (int64_t)p : (int64_t)eid_t[p];
                     float ee[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-                    mysc = invdeg[myi];
+                    mysc = (VARIANT == 7) ? 0.25f : invdeg[myi];
 #pragma unroll
                     for (int kk = 0; kk < K; ++kk) {
                         float h = b1[kk];
@@ -421,29 +423,36 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                         myh[kk] = fmaxf(h, 0.f) * mysc;
                     }
                 }
+                // lanes 0..15 of the row hold out-edges base..base+15 (zeros past the end: a dead slot multiplies row 0
+                // by 0); broadcasts with compile-time source lanes are one DPP move each (row_newbcast) -- with a runtime
+                // lane (__shfl) every one of the ten per edge was a ds_bpermute_b32 + s_waitcnt round trip
                 const int cnt = (end - base < 16) ? end - base : 16;
-                for (int u0 = 0; u0 < cnt; u0 += 4) {
-                    float4 gr[4];
-                    float sc[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int src = u0 + u;
-                        const int64_t i = __shfl(myi, src, 16);
-                        sc[u] = (src < cnt) ? __shfl(mysc, src, 16) : 0.f;
-                        gr[u] = ld4(g + (src < cnt ? i : 0) * ldg + c0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int src = u0 + u;
-#pragma unroll
-                        for (int kk = 0; kk < K; ++kk) {
-                            float h = __shfl(myh[kk], src, 16);
-                            if (src >= cnt) h = 0.f;
-                            acc[kk] = fma4(h, gr[u], acc[kk]);
-                        }
-                        acc[K] = fma4(sc[u], gr[u], acc[K]);
-                    }
+#define QOT_ADJ_EDGE(U)                                                                                  \
+                {                                                                                        \
+                    const int64_t i = (VARIANT == 1) ? (int64_t)(row16_bcast<U>(myi) & 1) : (int64_t)row16_bcast<U>(myi); \
+                    gr[(U) & 3] = ld4(g + i * ldg + c0);                                                 \
+                    sc[(U) & 3] = row16_bcast<U>(mysc);                                                  \
                 }
+#define QOT_ADJ_FMA(U)                                                                                   \
+                {                                                                                        \
+                    _Pragma("unroll") for (int kk = 0; kk < (VARIANT == 6 ? 1 : K); ++kk)                \
+                        acc[kk] = fma4(row16_bcast<U>(myh[kk]), gr[(U) & 3], acc[kk]);                   \
+                    acc[K] = fma4(sc[(U) & 3], gr[(U) & 3], acc[K]);                                     \
+                }
+#define QOT_ADJ_EDGE4(U0)                                                                                \
+                {                                                                                        \
+                    float4 gr[4];                                                                        \
+                    float sc[4];                                                                         \
+                    QOT_ADJ_EDGE(U0) QOT_ADJ_EDGE(U0 + 1) QOT_ADJ_EDGE(U0 + 2) QOT_ADJ_EDGE(U0 + 3)      \
+                    QOT_ADJ_FMA(U0) QOT_ADJ_FMA(U0 + 1) QOT_ADJ_FMA(U0 + 2) QOT_ADJ_FMA(U0 + 3)          \
+                }
+                QOT_ADJ_EDGE4(0)
+                if (cnt > 4) QOT_ADJ_EDGE4(4)
+                if (cnt > 8) QOT_ADJ_EDGE4(8)
+                if (cnt > 12) QOT_ADJ_EDGE4(12)
+#undef QOT_ADJ_EDGE4
+#undef QOT_ADJ_FMA
+#undef QOT_ADJ_EDGE
             }
             // channels c0..c0+3 of block kk: k = 64 kk + c0 + t -> group 8 kk + sub/2,
             // (r, hi) = (2 (sub&1) + t/2, t&1): two 8-byte stores per block, conflict-free
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        {
+        if (VARIANT != 2 && VARIANT != 5) {
             int ch = 0;
 #pragma unroll 1
             for (; ch + 1 < NCH; ch += 2) {
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         // reads of step s+1 are issued before the TPW MFMAs of step s (left to itself the compiler
         // reused ONE temporary and put `ds_read_b32; s_waitcnt lgkmcnt(0)` in front of every MFMA --
         // half of all MFMAs of this kernel waited for their own LDS read).
-        {
+        if (VARIANT != 3 && VARIANT != 5) {
             float abuf[2][TPW], xbuf[2];
             const float* xsl = xs + hi * 64 + ah * 32 + r31;          // row 2s + hi -> + 128 s
 #pragma unroll
@@ -1025,6 +1034,24 @@ extern "C" int qot_nnconv_adjoint_dw(const float* grad_out, int ld_g, const floa
     int grid = grid_for(N, 32);
     const int cap = num_cus() * kAdjBlocksPerCu;
     if (grid > cap) grid = cap;
+#ifdef QOT_DIAG
+    if (g_variant >= 11 && g_variant <= 17 && D == 4) {
+#define QOT_ADJ_V(V) nnconv_adjoint_dw64_kernel<4, V><<<grid, 512, 0, stream>>>(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, \
+            rowptr_t, col_t, eid_t, invdeg, w_perm, grad_x, workspace, N)
+        switch (g_variant) {
+            case 11: QOT_ADJ_V(1); break;
+            case 12: QOT_ADJ_V(2); break;
+            case 13: QOT_ADJ_V(3); break;
+            case 14: QOT_ADJ_V(4); break;
+            case 16: QOT_ADJ_V(6); break;
+            case 17: QOT_ADJ_V(7); break;
+            default: QOT_ADJ_V(5); break;
+        }
+#undef QOT_ADJ_V
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
+#endif
     QOT_DISPATCH_D(D, {
         if (kD <= 4)
             nnconv_adjoint_dw64_kernel<(kD <= 4 ? kD : 4)><<<grid, 512, 0, stream>>>(
