@@ -49,18 +49,18 @@ __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// Value of lane SRC (compile-time, 0..7) of every aligned 8-lane group, in all lanes of the group:
-// quad_perm broadcast inside the quads, row_half_mirror carries it to the other quad, a select keeps the
-// right one -- three VALU operations instead of a ds_bpermute_b32 round trip.  `upper` = (lane & 4) != 0.
+// Value of lane SRC (compile-time, 0..7) of every aligned 8-lane group, in all lanes of the group: two DPP moves
+// (`row_newbcast` of lane SRC into the lower half of the row -- bank mask 0x3 -- and of lane 8 + SRC into the upper
+// half -- bank mask 0xC -- of the same register), no select, no ds_bpermute_b32 round trip.  `upper` (= (lane & 4) != 0)
+// is no longer needed and kept for the call sites.
 template <int SRC>
-__device__ __forceinline__ float group8_bcast(float v, bool upper) {
-    const float t = dpp_move<(SRC & 3) * 0x55>(v);
-    const float w = dpp_move<0x141>(t);
-    return (upper == ((SRC & 4) != 0)) ? t : w;
+__device__ __forceinline__ int group8_bcast(int v, bool /*upper*/ = false) {
+    const int lo = __builtin_amdgcn_mov_dpp(v, 0x150 + SRC, 0xF, 0x3, false);     // upper half: don't care yet
+    return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + SRC, 0xF, 0xC, false);
 }
 template <int SRC>
-__device__ __forceinline__ int group8_bcast(int v, bool upper) {
-    return __builtin_bit_cast(int, group8_bcast<SRC>(__builtin_bit_cast(float, v), upper));
+__device__ __forceinline__ float group8_bcast(float v, bool /*upper*/ = false) {
+    return __builtin_bit_cast(float, group8_bcast<SRC>(__builtin_bit_cast(int, v)));
 }
 
 // Value of lane SRC (compile-time, 0..15) of every DPP row of 16 lanes, in all lanes of the row: ONE VALU move

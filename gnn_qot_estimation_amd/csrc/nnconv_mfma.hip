@@ -81,33 +81,31 @@ __device__ __forceinline__ void nnconv_gather_tile(
             }
         }
         const int cnt = (end - base < 8) ? end - base : 8;
-        const bool upper = (sub & 4) != 0;
         // lanes 0..7 of the group hold edges base..base+7; broadcasts with compile-time source lanes run on
         // the DPP path (as __shfl with a runtime lane each was a ds_bpermute_b32 round trip: ten per edge)
+        // dead slots (lane p >= end) carry myj = 0, h = 0 and scale = 0 from the prefetch above: their terms vanish
+        // without per-use selects (row 0 times zero)
 #define QOT_EDGE4(U0)                                                                                   \
         {                                                                                               \
             float4 xa[4], xb[4];                                                                        \
             float sc[4];                                                                                \
             int jj[4];                                                                                  \
-            jj[0] = group8_bcast<U0 + 0>(myj, upper); jj[1] = group8_bcast<U0 + 1>(myj, upper);         \
-            jj[2] = group8_bcast<U0 + 2>(myj, upper); jj[3] = group8_bcast<U0 + 3>(myj, upper);         \
-            sc[0] = group8_bcast<U0 + 0>(mysc, upper); sc[1] = group8_bcast<U0 + 1>(mysc, upper);       \
-            sc[2] = group8_bcast<U0 + 2>(mysc, upper); sc[3] = group8_bcast<U0 + 3>(mysc, upper);       \
+            jj[0] = group8_bcast<U0 + 0>(myj); jj[1] = group8_bcast<U0 + 1>(myj);                       \
+            jj[2] = group8_bcast<U0 + 2>(myj); jj[3] = group8_bcast<U0 + 3>(myj);                       \
+            sc[0] = group8_bcast<U0 + 0>(mysc); sc[1] = group8_bcast<U0 + 1>(mysc);                     \
+            sc[2] = group8_bcast<U0 + 2>(mysc); sc[3] = group8_bcast<U0 + 3>(mysc);                     \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
-                const bool live = U0 + u < cnt;                                                         \
-                const float* xr = x + (live ? (int64_t)jj[u] : 0) * ldx + c0;                           \
+                const float* xr = x + (int64_t)jj[u] * ldx + c0;                                        \
                 xa[u] = ld4(xr);                                                                        \
                 xb[u] = ld4(xr + 4);                                                                    \
-                if (!live) sc[u] = 0.f;                                                                 \
             }                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                          \
                 float h[4];                                                                             \
-                h[0] = group8_bcast<U0 + 0>(myh[kk], upper); h[1] = group8_bcast<U0 + 1>(myh[kk], upper); \
-                h[2] = group8_bcast<U0 + 2>(myh[kk], upper); h[3] = group8_bcast<U0 + 3>(myh[kk], upper); \
+                h[0] = group8_bcast<U0 + 0>(myh[kk]); h[1] = group8_bcast<U0 + 1>(myh[kk]);             \
+                h[2] = group8_bcast<U0 + 2>(myh[kk]); h[3] = group8_bcast<U0 + 3>(myh[kk]);             \
                 _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
-                    const float hv = (U0 + u < cnt) ? h[u] : 0.f;                                       \
-                    acc0[kk] = fma4(hv, xa[u], acc0[kk]);                                               \
-                    acc1[kk] = fma4(hv, xb[u], acc1[kk]);                                               \
+                    acc0[kk] = fma4(h[u], xa[u], acc0[kk]);                                             \
+                    acc1[kk] = fma4(h[u], xb[u], acc1[kk]);                                             \
                 }                                                                                       \
             }                                                                                           \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
@@ -536,9 +534,11 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                     for (int t = 0; t < TPW; ++t) abuf[cur ^ 1][t] = Ut[dwoff[sn & 3] + (sn >> 2) * 32 + t * 4096];
                     xbuf[cur ^ 1] = xsl[sn * 128];
                 }
+                __builtin_amdgcn_sched_barrier(0);      // the reads of step s+1 stay in front of the MFMAs of step s
 #pragma unroll
                 for (int t = 0; t < TPW; ++t)
                     dw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(abuf[cur][t], xbuf[cur], dw[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         lds_barrier();
