@@ -732,63 +732,71 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
                     for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
                 }
                 const int cnt = (end - base < 8) ? end - base : 8;
-                for (int u0 = 0; u0 < cnt; u0 += 4) {
-                    // four source rows in flight per destination group
-                    float4 xr0[4], xr1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int64_t j = __shfl(myj, u0 + u, 8);
-                        const float* xp = x + (u0 + u < cnt ? j : 0) * ldx + c0;
-                        xr0[u] = ld4(xp); xr1[u] = ld4(xp + 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool live = u0 + u < cnt;
-                        float ee[D];
-#pragma unroll
-                        for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, 8);
-                        const float xv[8] = {xr0[u].x, xr0[u].y, xr0[u].z, xr0[u].w, xr1[u].x, xr1[u].y, xr1[u].z, xr1[u].w};
-#pragma unroll
-                        for (int q = 0; q < KPL; ++q) {
-                            float pd[8];
-#pragma unroll
-                            for (int kk = 0; kk < 8; ++kk) {
-                                const int k = 8 * q + kk;
-                                float a = 0.f;
-                                if (k < K) {
-#pragma unroll
-                                    for (int t = 0; t < 8; ++t) a = fmaf(ga[k < K ? k : 0][t], xv[t], a);
-                                }
-                                pd[kk] = a;
-                            }
-                            // transpose-reduce 8 values over 8 lanes: lane s ends with the total of value s
-                            float t4[4];
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) {
-                                const float keep = (sub & 4) ? pd[m + 4] : pd[m];
-                                const float send = (sub & 4) ? pd[m] : pd[m + 4];
-                                t4[m] = keep + dpp_move<0x141>(send);      // partner 7 - sub (bit 2 differs): DPP, no LDS crossbar
-                            }
-                            float t2[2];
-#pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                const float keep = (sub & 2) ? t4[m + 2] : t4[m];
-                                const float send = (sub & 2) ? t4[m] : t4[m + 2];
-                                t2[m] = keep + dpp_move<0x4E>(send);       // partner sub ^ 2
-                            }
-                            const float keep = (sub & 1) ? t2[1] : t2[0];
-                            const float send = (sub & 1) ? t2[0] : t2[1];
-                            const float tot = keep + dpp_move<0xB1>(send);   // partner sub ^ 1; k = 8*q + sub
-                            float pre = brow[q];
-#pragma unroll
-                            for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);
-                            const float gh = (live && pre > 0.f && 8 * q + sub < K) ? tot * sc : 0.f;
-                            ab[q] += gh;
-#pragma unroll
-                            for (int d = 0; d < D; ++d) aw[q][d] = fmaf(gh, ee[d], aw[q][d]);
-                        }
-                    }
+                // four source rows in flight per destination group; lane s of the group holds edge s (zeros / row 0 past
+                // the end), broadcasts with compile-time lanes are DPP moves (with a runtime lane each was a
+                // ds_bpermute_b32 round trip: five per edge)
+#define QOT_GH_ONE(U)                                                                                             \
+                {                                                                                                 \
+                    const bool live = (U) < cnt;                                                                  \
+                    float ee[D];                                                                                  \
+                    _Pragma("unroll") for (int d = 0; d < D; ++d) ee[d] = group8_bcast<U>(mye[d]);                \
+                    const float2 xv2[4] = {make_float2(xr0[(U) & 3].x, xr0[(U) & 3].y), make_float2(xr0[(U) & 3].z, xr0[(U) & 3].w), \
+                                           make_float2(xr1[(U) & 3].x, xr1[(U) & 3].y), make_float2(xr1[(U) & 3].z, xr1[(U) & 3].w)}; \
+                    _Pragma("unroll") for (int q = 0; q < KPL; ++q) {                                             \
+                        float pd[8];                                                                              \
+                        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                        \
+                            const int k = 8 * q + kk;                                                             \
+                            float a = 0.f;                                                                        \
+                            if (k < K) {            /* two interleaved partial dots: packed FMAs */               \
+                                const int kc = k < K ? k : 0;                                                     \
+                                float2 a2 = make_float2(ga[kc][0] * xv2[0].x, ga[kc][1] * xv2[0].y);              \
+                                _Pragma("unroll") for (int t = 1; t < 4; ++t) {                                   \
+                                    a2.x = fmaf(ga[kc][2 * t], xv2[t].x, a2.x);                                   \
+                                    a2.y = fmaf(ga[kc][2 * t + 1], xv2[t].y, a2.y);                               \
+                                }                                                                                 \
+                                a = a2.x + a2.y;                                                                  \
+                            }                                                                                     \
+                            pd[kk] = a;                                                                           \
+                        }                                                                                         \
+                        /* transpose-reduce 8 values over 8 lanes: lane s ends with the total of value s */       \
+                        float t4[4];                                                                              \
+                        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                           \
+                            const float keep = (sub & 4) ? pd[m + 4] : pd[m];                                     \
+                            const float send = (sub & 4) ? pd[m] : pd[m + 4];                                     \
+                            t4[m] = keep + dpp_move<0x141>(send);      /* partner 7 - sub (bit 2 differs) */      \
+                        }                                                                                         \
+                        float t2[2];                                                                              \
+                        _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                           \
+                            const float keep = (sub & 2) ? t4[m + 2] : t4[m];                                     \
+                            const float send = (sub & 2) ? t4[m] : t4[m + 2];                                     \
+                            t2[m] = keep + dpp_move<0x4E>(send);       /* partner sub ^ 2 */                      \
+                        }                                                                                         \
+                        const float keep = (sub & 1) ? t2[1] : t2[0];                                             \
+                        const float send = (sub & 1) ? t2[0] : t2[1];                                             \
+                        const float tot = keep + dpp_move<0xB1>(send);   /* partner sub ^ 1; k = 8*q + sub */     \
+                        float pre = brow[q];                                                                      \
+                        _Pragma("unroll") for (int d = 0; d < D; ++d) pre = fmaf(wrow[q][d], ee[d], pre);         \
+                        const float gh = (live && pre > 0.f && 8 * q + sub < K) ? tot * sc : 0.f;                 \
+                        ab[q] += gh;                                                                              \
+                        _Pragma("unroll") for (int d = 0; d < D; ++d) aw[q][d] = fmaf(gh, ee[d], aw[q][d]);       \
+                    }                                                                                             \
                 }
+#define QOT_GH_LOAD(U)                                                                                            \
+                {                                                                                                 \
+                    const float* xp = x + (int64_t)group8_bcast<U>(myj) * ldx + c0;                               \
+                    xr0[(U) & 3] = ld4(xp); xr1[(U) & 3] = ld4(xp + 4);                                           \
+                }
+#define QOT_GH_EDGE4(U0)                                                                                          \
+                {                                                                                                 \
+                    float4 xr0[4], xr1[4];                                                                        \
+                    QOT_GH_LOAD(U0) QOT_GH_LOAD(U0 + 1) QOT_GH_LOAD(U0 + 2) QOT_GH_LOAD(U0 + 3)                   \
+                    QOT_GH_ONE(U0) QOT_GH_ONE(U0 + 1) QOT_GH_ONE(U0 + 2) QOT_GH_ONE(U0 + 3)                       \
+                }
+                QOT_GH_EDGE4(0)
+                if (cnt > 4) QOT_GH_EDGE4(4)
+#undef QOT_GH_EDGE4
+#undef QOT_GH_LOAD
+#undef QOT_GH_ONE
             }
         }
         lds_barrier();        // GAt / Gt are rewritten by the next tile
