@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 4          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 5          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -43,6 +43,7 @@ SIGNATURES = {
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_bwd_dst_workspace_floats": (_sz, [_i64, _int, _int]),
+    "qot_tconv_rows_per_block": (_int, [_int]),
     "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
                                  _p, _f, _f, _u64, _p, _p, _p, _int, _i64, _p, _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _i64, _p, _i64, _int,

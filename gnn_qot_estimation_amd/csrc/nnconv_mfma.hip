@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     unsigned long long t_prev = 0;
     if (VARIANT == 3) t_prev = __builtin_amdgcn_s_memtime();
 
-    if (VARIANT != 1) {
+    if (VARIANT != 1 && VARIANT != 4 && VARIANT != 5) {
         nnconv_gather_tile<D, TRANSPOSE>(At, x, ldx, ea, w1, b1, rowptr, col, eidx, invdeg, tile0, N, root0, root1);
     } else {
         for (int t = threadIdx.x; t < KM * 32; t += 256) At[t] = 1.0f + (float)(t & 7);
@@ -219,12 +219,22 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     for (; ch + NB <= NCH; ch += NB) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            if (ch + q + NB - 1 < NCH) {
+            if (ch + q + NB - 1 < NCH && VARIANT != 4 && VARIANT != 5) {       // 4 / 5: weight fragments not streamed
 #pragma unroll
                 for (int u = 0; u < CH; ++u) bb[(q + NB - 1) % NB][u] = wp[((ch + q + NB - 1) * CH + u) * 64];
             }
 #pragma unroll
-            for (int u = 0; u < CH; ++u) c = mfma_group(At4, kh * GM + (ch + q) * CH + u, hi, r31, bb[q][u], c);
+            for (int u = 0; u < CH; ++u) {
+                if (VARIANT == 5) {                                            // 5: operand tile not read either
+                    const float4 a = rb[u & 3], b = bb[q][u];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+                } else {
+                    c = mfma_group(At4, kh * GM + (ch + q) * CH + u, hi, r31, bb[q][u], c);
+                }
+            }
         }
     }
     // tail: chunks ch .. NCH-1 are already in buffers 0 .. (their loads were issued above)
@@ -932,12 +942,38 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     const ActParams ap = make_act(act, act_slope, act_p, act_seed, act_step);
 #ifdef QOT_DIAG
-    if (g_variant && D == 4 && !transpose) {
+    if (g_variant >= 100 && g_variant < 110 && D == 4 && !transpose) {      // 100 + v: variant v with ONE workgroup per CU
+        const int v = g_variant - 100, g1 = grid > num_cus() ? num_cus() : grid;
+        if (v == 0)
+            nnconv_mfma64_kernel<4, false, 0><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (v == 1)
+            nnconv_mfma64_kernel<4, false, 1><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (v == 4)
+            nnconv_mfma64_kernel<4, false, 4><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (v == 5)
+            nnconv_mfma64_kernel<4, false, 5><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else
+            nnconv_mfma64_kernel<4, false, 2><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
+    if (g_variant && g_variant < 10 && D == 4 && !transpose) {
         if (g_variant == 3)
             nnconv_mfma64_kernel<4, false, 3><<<grid, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else if (g_variant == 1)
             nnconv_mfma64_kernel<4, false, 1><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 4)
+            nnconv_mfma64_kernel<4, false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 5)
+            nnconv_mfma64_kernel<4, false, 5><<<grid, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else
             nnconv_mfma64_kernel<4, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(

@@ -4,9 +4,9 @@
 // materialisation [E,H], a 3-pass scatter softmax and a scatter_add become ONE pass over
 // the destination-sorted CSR.
 //
-// Mapping: a group of TPR = H/4 consecutive lanes owns one destination node; every lane
-// holds 4 channels (one 16-B load per row per lane -> a row read is one contiguous
-// H*4-byte burst).  64/TPR destinations per wave.  The edge embedding is never formed:
+// Mapping: a group of TPR = H/CPL consecutive lanes owns one destination node; every lane holds CPL = 4 channels
+// (one 16-B load per row per lane -> a row read is one contiguous H*4-byte burst; tconv_cpl below).  64/TPR
+// destinations per wave.  The edge embedding is never formed:
 //   <q_i, k_j + We ea> = <q_i, k_j> + <We^T q_i, ea>        (D-vector per destination)
 //   sum_e a_e (v_j + We ea_e) = sum_e a_e v_j + We (sum_e a_e ea_e)
 // so per edge only the 4 raw edge features are read.  Online softmax (running max / sum).
@@ -14,42 +14,67 @@
 
 namespace qot {
 
+// channels per lane.  8 from H = 64 on (half the lanes per destination, half the redundant softmax scalars per edge) was
+// measured and is SLOWER at cfg2 (fwd 32 -> 36-40 us, destination pass 44 -> 51-54 us, source pass 24 -> 24.5-26 us with
+// two or four rows in flight): fewer, longer waves at 3-4 waves per SIMD hide less of the dependent-load latency than
+// the instruction count saves.  The kernels stay written for either value.
+__host__ __device__ constexpr int tconv_cpl(int /*H*/) { return 4; }
+__host__ __device__ constexpr int tconv_rpb(int H) { return 256 / (H / tconv_cpl(H)); }  // destinations per workgroup
+
+template <int NV>
+__device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[NV]) {
+    float s = dot4(a[0], b[0]);
+#pragma unroll
+    for (int v = 1; v < NV; ++v) s += dot4(a[v], b[v]);
+    return s;
+}
+__device__ __forceinline__ float comp4(const float4& a, int c) { return c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w)); }
+
 template <int H, int D>
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v_,
     const float* __restrict__ skip, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap,
     float* __restrict__ out, float* __restrict__ stats, int64_t N, ActParams act) {
-    constexpr int TPR = H / 4;
+    constexpr int CPL = tconv_cpl(H), NV = CPL / 4;
+    constexpr int TPR = H / CPL;
     constexpr int RPB = 256 / TPR;
     const int sub = threadIdx.x % TPR;
     const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * RPB + threadIdx.x / TPR;
     if (i >= N) return;
     const float rs = rsqrtf((float)H);
-    const int c0 = 4 * sub;
+    const int c0 = CPL * sub;
     // table mode: q/k/v/skip are rows of a projected embedding table; rowmap = node -> table row
     // for this node, and `col` already holds the table row of every in-edge's source
     const int64_t ri = rowmap ? (int64_t)rowmap[i] : i;
 
-    float4 qi = scale4(rs, ld4(q + ri * ld + c0));
-    float wl[4][D];
+    float4 qi[NV];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int v = 0; v < NV; ++v) qi[v] = scale4(rs, ld4(q + ri * ld + c0 + 4 * v));
+    float wl[CPL][D];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
 #pragma unroll
         for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
     float qe[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        qe[d] = group_sum<TPR>(qi.x * wl[0][d] + qi.y * wl[1][d] + qi.z * wl[2][d] + qi.w * wl[3][d]);
+    for (int d = 0; d < D; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t = fmaf(comp4(qi[c >> 2], c & 3), wl[c][d], t);
+        qe[d] = group_sum<TPR>(t);
+    }
 
     float m = -INFINITY, l = 0.f;
-    float4 acc = f4zero();
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f4zero();
     float aacc[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) aacc[d] = 0.f;
 
-    // In-edges in batches of TPR: lane `sub` of the group prefetches edge `sub`'s (source row,
+    // In-edges in batches of BT: lane `sub` of the group prefetches edge `sub`'s (source row,
     // edge features) so the per-edge dependent chain (col -> rows) is paid once per batch, and
     // four source rows are in flight per group.
     const int beg = rowptr[i], end = rowptr[i + 1];
@@ -67,29 +92,34 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
             for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
         }
         const int cnt = (end - base < BT) ? end - base : BT;
-        for (int u0 = 0; u0 < cnt; u0 += 4) {
-            float4 kr[4], vr[4];
+        constexpr int UF = 4;            // source rows in flight per group (2 x UF x CPL registers)
+        for (int u0 = 0; u0 < cnt; u0 += UF) {
+            float4 kr[UF][NV], vr[UF][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 const int64_t j = __shfl(myj, u0 + u, TPR);
                 const int64_t jr = (u0 + u < cnt) ? j : 0;
-                kr[u] = ld4(k + jr * ld + c0);
-                vr[u] = ld4(v + jr * ld + c0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    kr[u][v] = ld4(k + jr * ld + c0 + 4 * v);
+                    vr[u][v] = ld4(v_ + jr * ld + c0 + 4 * v);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 if (u0 + u < cnt) {                           // group-uniform
                     float ee[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
-                    float s = group_sum<TPR>(dot4(qi, kr[u]));
+                    float s = group_sum<TPR>(dotv<NV>(qi, kr[u]));
 #pragma unroll
                     for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
                     float mn = fmaxf(m, s);
                     float sc = __expf(m - mn);
                     float pe = __expf(s - mn);
                     l = fmaf(l, sc, pe);
-                    acc = fma4(pe, vr[u], scale4(sc, acc));
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] = fma4(pe, vr[u][v], scale4(sc, acc[v]));
 #pragma unroll
                     for (int d = 0; d < D; ++d) aacc[d] = fmaf(pe, ee[d], aacc[d] * sc);
                     m = mn;
@@ -99,15 +129,18 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     }
     const float denom = l + 1e-16f;
     const float inv = 1.0f / denom;
-    float4 o = scale4(inv, acc);
-    float oc[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int v = 0; v < NV; ++v) {
+        const float4 o = scale4(inv, acc[v]);
+        float oc[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
-        for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[c][d], aacc[d] * inv, oc[c]);
-    float4 sk = ld4(skip + ri * ld + c0);
-    st4(out + i * H + c0, act_apply4(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w), act,
-                                     (uint64_t)(i * H + c0) >> 2));
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[4 * v + c][d], aacc[d] * inv, oc[c]);
+        const float4 sk = ld4(skip + ri * ld + c0 + 4 * v);
+        st4(out + i * H + c0 + 4 * v, act_apply4(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w), act,
+                                                 (uint64_t)(i * H + c0 + 4 * v) >> 2));
+    }
     if (sub == 0) {
         stats[2 * i] = (beg < end) ? m : 0.f;
         stats[2 * i + 1] = denom;
@@ -123,17 +156,19 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
 template <int H, int D>
 __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
-    const float* __restrict__ v, int ld, const float* __restrict__ ea,
+    const float* __restrict__ v_, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap, float* __restrict__ gq,
     float* __restrict__ gskip, int ld_g, float* __restrict__ escr, float* __restrict__ delta, float* __restrict__ pds, float* __restrict__ pal,
     int64_t N, const float* __restrict__ y_act, ActParams act, float* __restrict__ wedge_partials,
     int tile_n, int64_t tile_B, float* __restrict__ gpart) {
-    constexpr int TPR = H / 4;
+    constexpr int CPL = tconv_cpl(H), NV = CPL / 4;
+    constexpr int TPR = H / CPL;
     constexpr int RPB = 256 / TPR;
-    __shared__ float wred[RPB * H * D];
-    __shared__ float4 tred[2][256];
+    constexpr int DCH = D > 4 ? 4 : D;             // lin_edge partials meet in LDS in chunks of <= 4 edge features
+    __shared__ float wred[RPB * H * DCH];
+    __shared__ float4 tred[2][NV][256];
     const int sub = threadIdx.x % TPR;
     const int rloc = threadIdx.x / TPR;
     // Row of this lane group.  Tile mode (table mode with node_ids == arange(n) per graph, gpart !=
@@ -152,50 +187,67 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
             i = (int64_t)vb * RPB + rloc;
         }
     }
-    float4 rq = f4zero(), rg = f4zero();
-    const int c0 = 4 * sub;
+    float4 rq[NV], rg[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { rq[v] = f4zero(); rg[v] = f4zero(); }
+    const int c0 = CPL * sub;
     // rows past N (last block) contribute zeros to the block reduction below; no thread leaves
     // before the barrier (a wave can hold live and dead rows)
-    float wc[4][D];
+    float wc[CPL][D];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CPL; ++c)
 #pragma unroll
         for (int d = 0; d < D; ++d) wc[c][d] = 0.f;
     if (i < N) {
     const float rs = rsqrtf((float)H);
     const int64_t ri = rowmap ? (int64_t)rowmap[i] : i;
 
-    float4 qi = scale4(rs, ld4(q + ri * ld + c0));
-    float4 gi = ld4(g + i * H + c0);
-    if (y_act) {      // grad_out arrives for y = dropout(leaky_relu(conv)): go back through it here
-        const int64_t flat = i * H + c0;
-        const float4 yy = ld4(y_act + flat);
-        uint64_t z = 0;
-        if (act.thr16) z = act_hash64(act.seed, (uint64_t)act.step[0], (uint64_t)flat >> 2);
-        float vi[4] = {gi.x, gi.y, gi.z, gi.w};
-        const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+    float4 qi[NV], gi[NV];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool keep = act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= act.thr16) : true;
-            vi[c] = vi[c] * (keep ? act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : act.slope);
-        }
-        gi = make_float4(vi[0], vi[1], vi[2], vi[3]);
+    for (int v = 0; v < NV; ++v) {
+        qi[v] = scale4(rs, ld4(q + ri * ld + c0 + 4 * v));
+        gi[v] = ld4(g + i * H + c0 + 4 * v);
     }
-    float wl[4][D];
+    if (y_act) {      // grad_out arrives for y = dropout(leaky_relu(conv)): go back through it here
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int v = 0; v < NV; ++v) {
+            const int64_t flat = i * H + c0 + 4 * v;
+            const float4 yy = ld4(y_act + flat);
+            uint64_t z = 0;
+            if (act.thr16) z = act_hash64(act.seed, (uint64_t)act.step[0], (uint64_t)flat >> 2);
+            float vi[4] = {gi[v].x, gi[v].y, gi[v].z, gi[v].w};
+            const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool keep = act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= act.thr16) : true;
+                vi[c] = vi[c] * (keep ? act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : act.slope);
+            }
+            gi[v] = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        }
+    }
+    float wl[CPL][D];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
 #pragma unroll
         for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
     float qe[D], ge[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        qe[d] = group_sum<TPR>(qi.x * wl[0][d] + qi.y * wl[1][d] + qi.z * wl[2][d] + qi.w * wl[3][d]);
-        ge[d] = group_sum<TPR>(gi.x * wl[0][d] + gi.y * wl[1][d] + gi.z * wl[2][d] + gi.w * wl[3][d]);
+        float tq = 0.f, tg = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            tq = fmaf(comp4(qi[c >> 2], c & 3), wl[c][d], tq);
+            tg = fmaf(comp4(gi[c >> 2], c & 3), wl[c][d], tg);
+        }
+        qe[d] = group_sum<TPR>(tq);
+        ge[d] = group_sum<TPR>(tg);
     }
     const float m = stats[2 * i];
     const float inv = 1.0f / stats[2 * i + 1];
 
-    float4 a1 = f4zero(), a2 = f4zero();
+    float4 a1[NV], a2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { a1[v] = f4zero(); a2[v] = f4zero(); }
     float p1[D], p2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { p1[d] = 0.f; p2[d] = 0.f; }
@@ -216,24 +268,27 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
             for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
         }
         const int cnt = (end - base < BT) ? end - base : BT;
-        for (int u0 = 0; u0 < cnt; u0 += 4) {
-            float4 kr[4], vr[4];
+        constexpr int UF = 4;            // source rows in flight per group (2 x UF x CPL registers)
+        for (int u0 = 0; u0 < cnt; u0 += UF) {
+            float4 kr[UF][NV], vr[UF][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 const int64_t j = __shfl(myj, u0 + u, TPR);
                 const int64_t jr = (u0 + u < cnt) ? j : 0;
-                kr[u] = ld4(k + jr * ld + c0);
-                vr[u] = ld4(v + jr * ld + c0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    kr[u][v] = ld4(k + jr * ld + c0 + 4 * v);
+                    vr[u][v] = ld4(v_ + jr * ld + c0 + 4 * v);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 if (u0 + u < cnt) {
                     const int p = base + u0 + u;
                     float ee[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
-                    const float s_part = dot4(qi, kr[u]), da_part = dot4(gi, vr[u]);
-                    float s = group_sum<TPR>(s_part), da = group_sum<TPR>(da_part);
+                    float s = group_sum<TPR>(dotv<NV>(qi, kr[u])), da = group_sum<TPR>(dotv<NV>(gi, vr[u]));
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         s = fmaf(qe[d], ee[d], s);
@@ -242,8 +297,11 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
                     const float a = __expf(s - m) * inv;
                     const float ada = a * da;
                     sada += ada;
-                    a1 = fma4(ada, kr[u], a1);
-                    a2 = fma4(a, kr[u], a2);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        a1[v] = fma4(ada, kr[u][v], a1[v]);
+                        a2[v] = fma4(a, kr[u][v], a2[v]);
+                    }
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         p1[d] = fmaf(ada, ee[d], p1[d]);
@@ -260,18 +318,21 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
     float pd[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) pd[d] = p1[d] - sada * p2[d];
-    float4 r = sub4(a1, scale4(sada, a2));
-    float rc[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int v = 0; v < NV; ++v) {
+        const float4 r = sub4(a1[v], scale4(sada, a2[v]));
+        float rc[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int d = 0; d < D; ++d) rc[c] = fmaf(wl[c][d], pd[d], rc[c]);
-        rc[c] *= rs;
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) rc[c] = fmaf(wl[4 * v + c][d], pd[d], rc[c]);
+            rc[c] *= rs;
+        }
+        rq[v] = make_float4(rc[0], rc[1], rc[2], rc[3]);
+        rg[v] = gi[v];
+        if (!gpart) st4(gq + i * ld_g + c0 + 4 * v, rq[v]);
+        if (gskip) st4(gskip + i * ld_g + c0 + 4 * v, gi[v]);     // grad of the skip projection is grad_out itself
     }
-    rq = make_float4(rc[0], rc[1], rc[2], rc[3]);
-    rg = gi;
-    if (!gpart) st4(gq + i * ld_g + c0, rq);
-    if (gskip) st4(gskip + i * ld_g + c0, gi);        // grad of the skip projection is grad_out itself
     if (sub == 0) {
         delta[i] = sada;
 #pragma unroll
@@ -281,37 +342,49 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
         }
     }
     // grad of lin_edge.weight: gWe[c,d] += q_i[c]/sqrt(H) * pd_i[d] + g_i[c] * p2_i[d]
-    const float qc[4] = {qi.x, qi.y, qi.z, qi.w}, gc[4] = {gi.x, gi.y, gi.z, gi.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CPL; ++c)
 #pragma unroll
-        for (int d = 0; d < D; ++d) wc[c][d] = fmaf(qc[c], pd[d], gc[c] * p2[d]);
+        for (int d = 0; d < D; ++d) wc[c][d] = fmaf(comp4(qi[c >> 2], c & 3), pd[d], comp4(gi[c >> 2], c & 3) * p2[d]);
     }   // i < N
     if (wedge_partials) {
         // rows of the block meet in LDS, blocks in qot_tconv_bwd_dst's final fixed-order sum
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int d0 = 0; d0 < D; d0 += DCH) {
+            const int dc = (D - d0 < DCH) ? D - d0 : DCH;
+            if (d0) __syncthreads();
 #pragma unroll
-            for (int d = 0; d < D; ++d) wred[rloc * H * D + (c0 + c) * D + d] = wc[c][d];
-        __syncthreads();
-        for (int o = threadIdx.x; o < H * D; o += 256) {
-            float sacc = 0.f;
-            for (int r = 0; r < RPB; ++r) sacc += wred[r * H * D + o];
-            wedge_partials[(int64_t)blockIdx.x * H * D + o] = sacc;
+            for (int c = 0; c < CPL; ++c)
+#pragma unroll
+                for (int dd = 0; dd < DCH; ++dd)
+                    if (d0 + dd < D) wred[rloc * H * DCH + (c0 + c) * DCH + dd] = wc[c][d0 + dd];
+            __syncthreads();
+            for (int o = threadIdx.x; o < H * dc; o += 256) {
+                const int ch = o / dc, dd = o % dc;
+                float sacc = 0.f;
+                for (int r = 0; r < RPB; ++r) sacc += wred[r * H * DCH + ch * DCH + dd];
+                wedge_partials[(int64_t)blockIdx.x * H * D + ch * D + d0 + dd] = sacc;
+            }
         }
     }
     if (gpart) {       // rows of the RPB graphs meet in LDS (fixed order): one partial table row per workgroup
-        tred[0][threadIdx.x] = rq;
-        tred[1][threadIdx.x] = rg;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            tred[0][v][threadIdx.x] = rq[v];
+            tred[1][v][threadIdx.x] = rg[v];
+        }
         __syncthreads();
         if (rloc == 0) {
-            float4 a = tred[0][sub], bsum = tred[1][sub];
-            for (int r2 = 1; r2 < RPB; ++r2) {
-                a = add4(a, tred[0][r2 * TPR + sub]);
-                bsum = add4(bsum, tred[1][r2 * TPR + sub]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4 a = tred[0][v][sub], bsum = tred[1][v][sub];
+                for (int r2 = 1; r2 < RPB; ++r2) {
+                    a = add4(a, tred[0][v][r2 * TPR + sub]);
+                    bsum = add4(bsum, tred[1][v][r2 * TPR + sub]);
+                }
+                st4(gpart + prow * 4 * H + c0 + 4 * v, a);
+                st4(gpart + prow * 4 * H + 3 * H + c0 + 4 * v, bsum);
             }
-            st4(gpart + prow * 4 * H + c0, a);
-            st4(gpart + prow * 4 * H + 3 * H + c0, bsum);
         }
     }
 }
@@ -325,9 +398,10 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
     const int32_t* __restrict__ pos_t, const int32_t* __restrict__ qmap_t, float* __restrict__ gk,
     float* __restrict__ gv, int ld_g, int64_t N, int tile_n, int64_t tile_B, float* __restrict__ gpart) {
-    constexpr int TPR = H / 4;
+    constexpr int CPL = tconv_cpl(H), NV = CPL / 4;
+    constexpr int TPR = H / CPL;
     constexpr int RPB = 256 / TPR;
-    __shared__ float4 tred[2][256];
+    __shared__ float4 tred[2][NV][256];
     const int sub = threadIdx.x % TPR;
     const int rloc = threadIdx.x / TPR;
     int64_t j, prow = 0;
@@ -344,8 +418,10 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     }
     if (j >= N && !gpart) return;
     const float rs = rsqrtf((float)H);
-    const int c0 = 4 * sub;
-    float4 ak = f4zero(), av = f4zero();
+    const int c0 = CPL * sub;
+    float4 ak[NV], av[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { ak[v] = f4zero(); av[v] = f4zero(); }
     int beg = 0, end = 0;
     if (j < N) { beg = rowptr_t[j]; end = rowptr_t[j + 1]; }
     constexpr int BT = (TPR < 16) ? TPR : 16;
@@ -361,42 +437,58 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
             myds = mya * (escr[2 * p + 1] - delta[myi]) * rs;
         }
         const int cnt = (end - base < BT) ? end - base : BT;
-        for (int u0 = 0; u0 < cnt; u0 += 4) {
-            float4 gr[4], qr[4];
+        constexpr int UF = 4;
+        for (int u0 = 0; u0 < cnt; u0 += UF) {
+            float4 gr[UF][NV], qr[UF][NV];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 const int64_t i = __shfl(myi, u0 + u, TPR);
                 const int64_t iq = __shfl(myq, u0 + u, TPR);
                 const bool live = u0 + u < cnt;
-                gr[u] = ld4(g + (live ? i : 0) * ld_go + c0);
-                qr[u] = ld4(q + (live ? iq : 0) * ld + c0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    gr[u][v] = ld4(g + (live ? i : 0) * ld_go + c0 + 4 * v);
+                    qr[u][v] = ld4(q + (live ? iq : 0) * ld + c0 + 4 * v);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UF; ++u) {
                 const bool live = u0 + u < cnt;
                 const float a = live ? __shfl(mya, u0 + u, TPR) : 0.f;
                 const float ds = live ? __shfl(myds, u0 + u, TPR) : 0.f;
-                av = fma4(a, gr[u], av);
-                ak = fma4(ds, qr[u], ak);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    av[v] = fma4(a, gr[u][v], av[v]);
+                    ak[v] = fma4(ds, qr[u][v], ak[v]);
+                }
             }
         }
     }
     if (!gpart) {
-        st4(gk + j * ld_g + c0, ak);
-        st4(gv + j * ld_g + c0, av);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            st4(gk + j * ld_g + c0 + 4 * v, ak[v]);
+            st4(gv + j * ld_g + c0 + 4 * v, av[v]);
+        }
         return;
     }
-    tred[0][threadIdx.x] = ak;
-    tred[1][threadIdx.x] = av;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        tred[0][v][threadIdx.x] = ak[v];
+        tred[1][v][threadIdx.x] = av[v];
+    }
     __syncthreads();
     if (rloc == 0) {
-        float4 a = tred[0][sub], bsum = tred[1][sub];
-        for (int r2 = 1; r2 < RPB; ++r2) {
-            a = add4(a, tred[0][r2 * TPR + sub]);
-            bsum = add4(bsum, tred[1][r2 * TPR + sub]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 a = tred[0][v][sub], bsum = tred[1][v][sub];
+            for (int r2 = 1; r2 < RPB; ++r2) {
+                a = add4(a, tred[0][v][r2 * TPR + sub]);
+                bsum = add4(bsum, tred[1][v][r2 * TPR + sub]);
+            }
+            st4(gpart + prow * 4 * H + H + c0 + 4 * v, a);
+            st4(gpart + prow * 4 * H + 2 * H + c0 + 4 * v, bsum);
         }
-        st4(gpart + prow * 4 * H + H + c0, a);
-        st4(gpart + prow * 4 * H + 2 * H + c0, bsum);
     }
 }
 
@@ -524,7 +616,7 @@ extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, con
     if (N == 0) return QOT_OK;
     if (!q || !k || !v || !skip || !out || !stats || !w_edge || (ld & 3)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
-        constexpr int RPB = 256 / (kH / 4);
+        constexpr int RPB = tconv_rpb(kH);
         tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
             q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N,
             make_act(act, act_slope, act_p, act_seed, act_step));
@@ -552,7 +644,7 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
     const ActParams ap = make_act(y_act ? 1 : 0, act_slope, act_p, act_seed, act_step);
     int blocks = 0;
     QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
-        constexpr int RPB = 256 / (kH / 4);
+        constexpr int RPB = tconv_rpb(kH);
         blocks = grad_part ? tile_n * grid_for(tile_B, RPB) : grid_for(N, RPB);
         tconv_bwd_dst_kernel<kH, kD><<<blocks, 256, 0, stream>>>(
             grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, grad_skip, ld_g, escr,
@@ -576,11 +668,18 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
     return QOT_OK;
 }
 
+// destinations per workgroup of the TransformerConv kernels at width H (table mode pre-reduces the table gradient over
+// that many graphs: grad_part is [ceil(tile_B / RPB), tile_n, 4H])
+extern "C" int qot_tconv_rows_per_block(int H) {
+    if (H != 16 && H != 32 && H != 64 && H != 128 && H != 256) return 0;
+    return tconv_rpb(H);
+}
+
 // floats of workspace qot_tconv_bwd_dst needs when grad_w_edge is requested (tile mode: pass
-// N = tile_n * ceil(tile_B / RPB) * RPB, RPB = 1024 / H)
+// N = tile_n * ceil(tile_B / RPB) * RPB, RPB = qot_tconv_rows_per_block(H))
 extern "C" size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D) {
     if (N <= 0 || H < 4 || D <= 0) return 0;
-    const int64_t rpb = 256 / (H / 4) > 0 ? 256 / (H / 4) : 1;
+    const int64_t rpb = tconv_rpb(H);
     const int64_t blocks = (N + rpb - 1) / rpb;
     const int64_t groups = (blocks + kWedgeGroup - 1) / kWedgeGroup;
     return (size_t)(blocks + groups) * (size_t)H * (size_t)D;
@@ -597,7 +696,7 @@ extern "C" int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* 
         return QOT_ERR_BADARG;
     if (grad_part && (tile_n <= 0 || tile_B <= 0 || (int64_t)tile_n * tile_B != N)) return QOT_ERR_BADARG;
     QOT_DISPATCH_H(H, {
-        constexpr int RPB = 256 / (kH / 4);
+        constexpr int RPB = tconv_rpb(kH);
         const int blocks = grad_part ? tile_n * grid_for(tile_B, RPB) : grid_for(N, RPB);
         tconv_bwd_src_kernel<kH><<<blocks, 256, 0, (hipStream_t)stream>>>(
             grad_out, ld_go, q, ld, escr, delta, rowptr_t, col_t, pos_t, qmap_t, grad_k, grad_v, ld_g, N, tile_n,

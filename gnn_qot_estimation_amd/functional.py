@@ -274,7 +274,7 @@ class TConvFn(torch.autograd.Function):
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
         gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
-        rpb = 1024 // H                                   # destinations per workgroup
+        rpb = _lib.load().qot_tconv_rows_per_block(H)     # destinations per workgroup
         tiled = maps is not None
         if tiled:
             # table gradient = sum over graphs: pre-reduced over `rpb` graphs inside the kernels

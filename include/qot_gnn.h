@@ -45,7 +45,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 4
+#define QOT_ABI_VERSION 5
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -132,11 +132,14 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
  * (fixed-order block partials; workspace qot_tconv_bwd_dst_workspace_floats(N,H,D) floats),
  * replacing qot_tconv_wedge_grad.
  * Tile mode (grad_part != NULL; table mode with node_ids == arange(tile_n) for each of the tile_B graphs,
- * N = tile_n * tile_B): a workgroup takes node r of RPB = 1024/H consecutive graphs and pre-reduces the
+ * N = tile_n * tile_B): a workgroup takes node r of RPB = qot_tconv_rows_per_block(H) consecutive graphs and pre-reduces the
  * table gradient over them: grad_part[ceil(tile_B/RPB), tile_n, 4H] receives the partial sums of
  * grad_q (columns 0..H) and grad_skip (3H..4H) here and of grad_k / grad_v (H..3H) in qot_tconv_bwd_src;
  * the caller sums its first axis.  grad_q may then be NULL; grad_skip[N,H] is still written per node
  * (the source pass gathers it). */
+/* destinations per workgroup of the TransformerConv kernels at width H (1024/H today; callers size grad_part and the
+ * workspace from this query, not from the formula); 0 for an unsupported width */
+int qot_tconv_rows_per_block(int H);
 size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D);
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,

@@ -23,7 +23,9 @@ def t(iters=20):
     torch.cuda.synchronize(); st.record()
     for _ in range(iters): run()
     en.record(); torch.cuda.synchronize(); return st.elapsed_time(en) / iters * 1e3
-names = {0: "full", 1: "mfma only (no gather)", 2: "gather only (no mfma)"}
+names = {0: "full", 1: "mfma only (no gather)", 2: "gather only (no mfma)", 100: "full, 1 WG/CU", 101: "mfma only, 1 WG/CU",
+         102: "gather only, 1 WG/CU", 4: "mfma only, B not streamed", 5: "mfma only, no A reads, no B", 104: "mfma only, B not streamed, 1 WG/CU",
+         105: "mfma only, no A no B, 1 WG/CU"}
 res = {v: [] for v in names}
 for rnd in range(5):
     for v in names:
