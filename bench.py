@@ -38,8 +38,8 @@ CFG = dict(cfg=2, B=1024, n=100, e=400, H=64, D=4, out=3, layers=2, dropout=0.5)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)       # ~30 ms: the part needs ~12 ms of load to reach its clock
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--cpu-sample-graphs", type=int, default=64)
