@@ -641,7 +641,20 @@ __global__ void adj_slab_final_params_kernel(const float* __restrict__ slabs, in
 // are summed in a fixed order afterwards (bitwise reproducible, no float atomics).
 constexpr int kGaLd = 516;    // padded GA row (floats): rows 4 banks apart
 
-template <int D>
+#ifdef QOT_DIAG
+#define GH_STAMP(slot)                                                               \
+    if (VARIANT == 1) {                                                              \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[slot], _t - t_prev);        \
+        t_prev = _t;                                                                 \
+    }
+#else
+#define GH_STAMP(slot)
+#endif
+// VARIANT (diagnostic build only): 0 production; 1 phase stamps (g_stamps: g tile load+store, barrier, GA MFMA phase, barrier,
+// dot phase, end barrier); 2 no dot phase; 3 no GA MFMA phase; 4 GA phase without its LDS stores; 5 GA phase with the weight
+// fragments of block 0 reused (no L2 stream)
+template <int D, int VARIANT = 0>
 __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
     const float* __restrict__ g, int ldg, const float* __restrict__ x, int ldx, const float* __restrict__ ea,
     const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
@@ -679,6 +692,18 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
         if (tile < 0) break;
         const int64_t tile0 = tile * 32;
         const int64_t i = tile0 + il;
+        unsigned long long t_prev = 0;
+        if (VARIANT == 1) t_prev = __builtin_amdgcn_s_memtime();
+        // Weight fragments of this wave's first GA block are requested before anything else of the tile, those of block
+        // t + 1 before the MFMAs of block t (two buffers).  The stream itself is what this phase waits for: 128 KB of
+        // fragments per 32-row tile from L2 (ablation: 92.8 us, 63.3 us with the stream served from L1; requesting all four
+        // blocks up front only moves the wait in front of the g tile, and spills).
+        float4 bf[2][8];
+        {
+            const float4* bp = reinterpret_cast<const float4*>(Bp) + (int64_t)(wave * NBW) * 8 * 64 + lane;
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) bf[0][gq] = bp[gq * 64];
+        }
         // 1. g tile -> LDS (fragment-grouped, group index = sub)
         {
             float4 g0 = f4zero(), g1 = f4zero();
@@ -686,39 +711,45 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
             Gt4[at4_slot(sub, 0, il)] = make_float4(g0.x, g0.z, g1.x, g1.z);
             Gt4[at4_slot(sub, 1, il)] = make_float4(g0.y, g0.w, g1.y, g1.w);
         }
+        GH_STAMP(0)
         lds_barrier();
+        GH_STAMP(1)
         // 2. GA tile on the matrix cores
-        {
+        if (VARIANT != 3) {
             float4 af[8];
 #pragma unroll
             for (int gq = 0; gq < 8; ++gq) af[gq] = Gt4[at4_slot(gq, hi, r31)];
 #pragma unroll
             for (int t = 0; t < NBW; ++t) {
                 const int nb = wave * NBW + t;
-                const float4* bp = reinterpret_cast<const float4*>(Bp) + (int64_t)nb * 8 * 64 + lane;
-                float4 bf[8];
+                if (t + 1 < NBW) {
+                    const float4* bp = reinterpret_cast<const float4*>(Bp) +
+                                       (int64_t)((VARIANT == 5) ? wave * NBW : nb + 1) * 8 * 64 + lane;
 #pragma unroll
-                for (int gq = 0; gq < 8; ++gq) bf[gq] = bp[gq * 64];
+                    for (int gq = 0; gq < 8; ++gq) bf[(t + 1) & 1][gq] = bp[gq * 64];
+                }
                 f32x16 c;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
                 for (int gq = 0; gq < 8; ++gq) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].x, bf[gq].x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].y, bf[gq].y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].z, bf[gq].z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].w, bf[gq].w, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].x, bf[t & 1][gq].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].y, bf[t & 1][gq].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].z, bf[t & 1][gq].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gq].w, bf[t & 1][gq].w, c, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    GAt[row * LDGA + nb * 32 + r31] = c[r];
+                    if (VARIANT != 4 || c[r] == 12345.f) GAt[row * LDGA + nb * 32 + r31] = c[r];
                 }
             }
         }
+        GH_STAMP(2)
         lds_barrier();
+        GH_STAMP(3)
         // 3. per-edge dots
-        if (i < N) {
+        if (i < N && VARIANT != 2) {
             float ga[K][8];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -809,7 +840,9 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
 #undef QOT_GH_ONE
             }
         }
+        GH_STAMP(4)
         lds_barrier();        // GAt / Gt are rewritten by the next tile
+        GH_STAMP(5)
     }
     // block partial: sum the 32 lane groups (fixed order) -> partials[blk][K*(D+1)]
     float* red = GAt;
@@ -1023,6 +1056,22 @@ extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const flo
     int grid = grid_for(N > 0 ? N : 1, 32);
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     const int K = 2 * D;
+#ifdef QOT_DIAG
+    if (g_variant >= 31 && g_variant <= 35 && D == 4) {
+#define QOT_GH_V(V) nnconv_gradh64_kernel<4, V><<<grid, 256, 0, stream>>>(grad_out, ld_g, x, ld_x, edge_attr, w1, b1, rowptr, col, \
+                                                                        eid, invdeg, b_perm, workspace, N)
+        switch (g_variant) {
+            case 31: QOT_GH_V(1); break;
+            case 32: QOT_GH_V(2); break;
+            case 33: QOT_GH_V(3); break;
+            case 34: QOT_GH_V(4); break;
+            default: QOT_GH_V(5); break;
+        }
+#undef QOT_GH_V
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
+#endif
     QOT_DISPATCH_D(D, {
         if (kD <= 4)
             nnconv_gradh64_kernel<(kD <= 4 ? kD : 4)><<<grid, 256, 0, stream>>>(
