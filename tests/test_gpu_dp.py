@@ -156,3 +156,41 @@ def test_two_rank_lightpath_epoch_with_lut_less_shards_matches_single_process():
     assert rel_err(got["rm"], model.norm1.module.running_mean.cpu()) < 2e-5
     assert rel_err(got["rv"], model.norm1.module.running_var.cpu()) < 2e-5
     assert rel_err(got["param"], flat.flat_param.cpu()) < 5e-5
+
+
+# --------------------------------------------------------------------------- RCCL itself, as far as one GPU allows
+def _rccl_world1_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from gnn_qot_estimation_amd import dp
+        dev = torch.device("cuda:0")
+        full, model = _build("topo", dev)
+        flat = dp.FlatModel(model)
+        flat.broadcast_params()
+        flat.zero_grad()
+        F.smooth_l1_loss(model(full.to(dev)), full.y.view(-1, 3).to(dev)).backward()
+        before = flat.flat_grad.clone()
+        flat.all_reduce_grads()
+        scale = dp.loss_scale(5, dev)
+        torch.cuda.synchronize()
+        ret["mode"] = dp.reduce_mode(flat.flat_grad)
+        ret["same"] = bool(torch.equal(before, flat.flat_grad))
+        ret["scale"] = float(scale)
+        ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_group_runs_the_avg_all_reduce():
+    """The nccl (= RCCL) backend at world size 1 on the one GPU this box has: the library loads, a communicator is
+    created, ``ReduceOp.AVG`` is accepted (``dp.reduce_mode`` == "avg"), the flat-gradient all-reduce and the loss-scale
+    exchange run on the device and leave a single rank's values unchanged.  What stays unexercised until a multi-GPU node
+    runs it is the exchange between ranks."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_world1_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        got = dict(ret)
+    assert got["backend"] == "nccl" and got["mode"] == "avg"
+    assert got["same"] and abs(got["scale"] - 1.0) < 1e-6
