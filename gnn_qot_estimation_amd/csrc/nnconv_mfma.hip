@@ -34,7 +34,9 @@ namespace qot {
 // h = relu(W1 ea + b1) once; the per-edge loop then only broadcasts (8-lane shuffles) and
 // streams the 256-B source rows, four edges in flight per group.
 // Returns the destination's own row (root block) in registers; blocks 0..K go to LDS.
-template <int D, bool TRANSPOSE>
+// GV (diagnostic build only): 6 every gathered row read from one of two hot addresses; 7 arithmetic ids instead of the
+// index chain; 8 one of the K weighted sums only
+template <int D, bool TRANSPOSE, int GV = 0>
 __device__ __forceinline__ void nnconv_gather_tile(
     float* __restrict__ At, const float* __restrict__ x, int ldx, const float* __restrict__ ea,
     const float* __restrict__ w1, const float* __restrict__ b1, const int32_t* __restrict__ rowptr,
@@ -66,8 +68,8 @@ __device__ __forceinline__ void nnconv_gather_tile(
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
         if (p < end) {
-            myj = col[p];
-            const int64_t e = eidx[p];
+            myj = (GV == 7) ? (int)(i ^ (p & 31)) : col[p];
+            const int64_t e = (GV == 7) ? (int64_t)p : (int64_t)eidx[p];
             float ee[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
@@ -95,11 +97,11 @@ __device__ __forceinline__ void nnconv_gather_tile(
             sc[0] = group8_bcast<U0 + 0>(mysc); sc[1] = group8_bcast<U0 + 1>(mysc);                     \
             sc[2] = group8_bcast<U0 + 2>(mysc); sc[3] = group8_bcast<U0 + 3>(mysc);                     \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
-                const float* xr = x + (int64_t)jj[u] * ldx + c0;                                        \
+                const float* xr = x + (int64_t)(GV == 6 ? (jj[u] & 1) : jj[u]) * ldx + c0;              \
                 xa[u] = ld4(xr);                                                                        \
                 xb[u] = ld4(xr + 4);                                                                    \
             }                                                                                           \
-            _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                          \
+            _Pragma("unroll") for (int kk = 0; kk < (GV == 8 ? 1 : K); ++kk) {                          \
                 float h[4];                                                                             \
                 h[0] = group8_bcast<U0 + 0>(myh[kk]); h[1] = group8_bcast<U0 + 1>(myh[kk]);             \
                 h[2] = group8_bcast<U0 + 2>(myh[kk]); h[3] = group8_bcast<U0 + 3>(myh[kk]);             \
@@ -134,7 +136,7 @@ __device__ __forceinline__ void nnconv_gather_tile(
 #ifdef QOT_DIAG
 __device__ unsigned long long g_stamps[8];
 #define QOT_STAMP(slot)                                                              \
-    if (VARIANT == 3) {                                                              \
+    if (VARIANT == 3 || VARIANT == 9) {                                              \
         unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[slot], _t - t_prev);        \
         t_prev = _t;                                                                 \
@@ -167,30 +169,18 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     const int64_t tile0 = tile * 32;
     float4 root0, root1;
     unsigned long long t_prev = 0;
-    if (VARIANT == 3) t_prev = __builtin_amdgcn_s_memtime();
+    if (VARIANT == 3 || VARIANT == 9) t_prev = __builtin_amdgcn_s_memtime();
 
-    if (VARIANT != 1 && VARIANT != 4 && VARIANT != 5) {
-        nnconv_gather_tile<D, TRANSPOSE>(At, x, ldx, ea, w1, b1, rowptr, col, eidx, invdeg, tile0, N, root0, root1);
+    if (VARIANT != 1 && VARIANT != 4 && VARIANT != 5 && VARIANT != 9) {
+        nnconv_gather_tile<D, TRANSPOSE, (VARIANT >= 6 && VARIANT <= 8) ? VARIANT : 0>(At, x, ldx, ea, w1, b1, rowptr, col, eidx, invdeg, tile0, N, root0, root1);
     } else {
         for (int t = threadIdx.x; t < KM * 32; t += 256) At[t] = 1.0f + (float)(t & 7);
         root0 = root1 = make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    QOT_STAMP(0)
-    __syncthreads();
-    QOT_STAMP(1)
-    if (VARIANT == 2) {   // ablation: gather only
-        if (threadIdx.x < 32 && tile0 + threadIdx.x < N) out[(tile0 + threadIdx.x) * 64] = At[threadIdx.x * 33] + root0.x;
-        __syncthreads();
-        continue;
-    }
-
     const float4* At4 = reinterpret_cast<const float4*>(At);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nh = wave & 1, kh = wave >> 1;
     const int r31 = lane & 31, hi = lane >> 5;
-    f32x16 c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = 0.f;
     // Wp: [nh][group g of 4 k-steps][lane][4]; wave (nh, kh) owns main groups kh*GM.. and
     // root groups (2*GM + kh*4)..
     const float4* wpn = reinterpret_cast<const float4*>(Wp) + (int64_t)nh * (2 * GM + 8) * 64 + lane;
@@ -199,11 +189,13 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     // outside the tile loop, spilled, and reloaded from scratch -- with a full wait each -- every tile)
     const float4* rbp = wpn + (int64_t)(2 * GM + kh * 4) * 64;
     asm volatile("" : "+v"(rbp));          // opaque: one live base per tile, the four offsets stay immediates
+    // The first weight fragments of the tile (root block + three chunks) are requested BEFORE the barrier that
+    // publishes the operand tile, and that barrier orders LDS traffic only: requested behind a __syncthreads() their
+    // L2 round trip was exposed once per tile, now it runs while the wave waits for the slowest gatherer.
     float4 rb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) rb[u] = rbp[u * 64];
-    // B fragments (L2) of chunk ch+1 are requested before the 4*CH MFMAs of chunk ch issue
-    // B fragments are requested TWO chunks (32 MFMAs, ~2000 cycles) ahead, three buffers rotating with
+    // B fragments are requested NB - 1 chunks (48 MFMAs, ~3000 cycles) ahead, NB buffers rotating with
     // compile-time roles: an L2 round trip is then covered by this wave's own MFMAs, so a workgroup keeps
     // the pipe fed while its CU-mate is gathering (with one chunk of lookahead the MFMA phase only ran at
     // full rate when both workgroups were in it).
@@ -214,18 +206,30 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     for (int q = 0; q < NB - 1; ++q)
 #pragma unroll
         for (int u = 0; u < CH; ++u) bb[q][u] = wp[(q * CH + u) * 64];
+    QOT_STAMP(0)
+    lds_barrier();
+    QOT_STAMP(1)
+    if (VARIANT == 2) {   // ablation: gather only
+        if (threadIdx.x < 32 && tile0 + threadIdx.x < N) out[(tile0 + threadIdx.x) * 64] = At[threadIdx.x * 33] + root0.x + rb[0].x + bb[0][0].x;
+        __syncthreads();
+        continue;
+    }
+
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
     int ch = 0;
 #pragma unroll 1
     for (; ch + NB <= NCH; ch += NB) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            if (ch + q + NB - 1 < NCH && VARIANT != 4 && VARIANT != 5) {       // 4 / 5: weight fragments not streamed
+            if (ch + q + NB - 1 < NCH && VARIANT != 4 && VARIANT != 5 && VARIANT != 9) {       // 4 / 5: weight fragments not streamed
 #pragma unroll
                 for (int u = 0; u < CH; ++u) bb[(q + NB - 1) % NB][u] = wp[((ch + q + NB - 1) * CH + u) * 64];
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                if (VARIANT == 5) {                                            // 5: operand tile not read either
+                if (VARIANT == 5 || VARIANT == 9) {                            // 5 / 9: operand tile not read either
                     const float4 a = rb[u & 3], b = bb[q][u];
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
@@ -989,6 +993,9 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
         else if (v == 5)
             nnconv_mfma64_kernel<4, false, 5><<<g1, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (v == 9)
+            nnconv_mfma64_kernel<4, false, 9><<<g1, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else
             nnconv_mfma64_kernel<4, false, 2><<<g1, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
@@ -1007,6 +1014,18 @@ extern "C" int qot_nnconv_fused(const float* x, int ld_x, const float* edge_attr
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else if (g_variant == 5)
             nnconv_mfma64_kernel<4, false, 5><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 6)
+            nnconv_mfma64_kernel<4, false, 6><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 7)
+            nnconv_mfma64_kernel<4, false, 7><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 8)
+            nnconv_mfma64_kernel<4, false, 8><<<grid, 256, 0, (hipStream_t)stream>>>(
+                x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
+        else if (g_variant == 9)
+            nnconv_mfma64_kernel<4, false, 9><<<grid, 256, 0, (hipStream_t)stream>>>(
                 x, ld_x, edge_attr, w1, b1, rowptr, col, edge_ids, invdeg, w_perm, bias, out, N, ap);
         else
             nnconv_mfma64_kernel<4, false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(

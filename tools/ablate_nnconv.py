@@ -25,7 +25,7 @@ def t(iters=20):
     en.record(); torch.cuda.synchronize(); return st.elapsed_time(en) / iters * 1e3
 names = {0: "full", 1: "mfma only (no gather)", 2: "gather only (no mfma)", 100: "full, 1 WG/CU", 101: "mfma only, 1 WG/CU",
          102: "gather only, 1 WG/CU", 4: "mfma only, B not streamed", 5: "mfma only, no A reads, no B", 104: "mfma only, B not streamed, 1 WG/CU",
-         105: "mfma only, no A no B, 1 WG/CU"}
+         105: "mfma only, no A no B, 1 WG/CU", 6: "full, gathered rows hot", 7: "full, no index chain", 8: "full, one of K sums"}
 res = {v: [] for v in names}
 for rnd in range(5):
     for v in names:
@@ -38,14 +38,16 @@ for v, n in names.items():
 # per-phase stamps (diagnostic build: shares, not absolute time)
 import numpy as np
 lib.qot_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.qot_debug_set_variant(3); run(); torch.cuda.synchronize()
-lib.qot_debug_stamps(None, 1); run(); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 8)(); lib.qot_debug_stamps(ctypes.cast(buf, ctypes.c_void_p), 0)
-lib.qot_debug_set_variant(0)
 tiles = (N + 31) // 32
-names = ["gather", "barrier after gather", "mfma main loop", "barrier before root", "root write+barrier+mfma",
+names = ["gather (+ first weight requests)", "barrier after gather", "mfma main loop", "barrier before root", "root write+barrier+mfma",
          "reduce+epilogue", "end barrier"]
-tot = sum(buf[:7])
-for n, v in zip(names, buf[:7]):
-    print(f"  {n:28s} {v / (tiles * 4):9.0f} cycles/wave/tile  {100.0 * v / tot:5.1f}%")
-print(f"  total {tot / (tiles * 4):9.0f} cycles/wave/tile; tiles per WG {tiles / 512:.2f}")
+for v, title, wgs in ((3, "full kernel, 2 WG/CU", 512), (9, "no gather / A reads / B stream, 2 WG/CU", 512), (109, "no gather / A reads / B stream, 1 WG/CU", 256)):
+    lib.qot_debug_set_variant(v); run(); torch.cuda.synchronize()
+    lib.qot_debug_stamps(None, 1); run(); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)(); lib.qot_debug_stamps(ctypes.cast(buf, ctypes.c_void_p), 0)
+    tot = sum(buf[:7])
+    print(title)
+    for n, val in zip(names, buf[:7]):
+        print(f"  {n:34s} {val / (tiles * 4):9.0f} ticks/wave/tile  {100.0 * val / tot:5.1f}%")
+    print(f"  total {tot / (tiles * 4):9.0f} ticks/wave/tile; tiles per WG {tiles / wgs:.2f}")
+lib.qot_debug_set_variant(0)
