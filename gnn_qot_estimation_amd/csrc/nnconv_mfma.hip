@@ -102,17 +102,26 @@ __device__ __forceinline__ void nnconv_gather_tile(
                 xb[u] = ld4(xr + 4);                                                                    \
             }                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < (GV == 8 ? 1 : K); ++kk) {                          \
-                float h[4];                                                                             \
-                h[0] = group8_bcast<U0 + 0>(myh[kk]); h[1] = group8_bcast<U0 + 1>(myh[kk]);             \
-                h[2] = group8_bcast<U0 + 2>(myh[kk]); h[3] = group8_bcast<U0 + 3>(myh[kk]);             \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
-                    acc0[kk] = fma4(h[u], xa[u], acc0[kk]);                                             \
-                    acc1[kk] = fma4(h[u], xb[u], acc1[kk]);                                             \
-                }                                                                                       \
+                const float h0 = group8_bcast<U0 + 0>(myh[kk]), h1 = group8_bcast<U0 + 1>(myh[kk]);     \
+                acc0[kk] = fma4(h0, xa[0], acc0[kk]); acc1[kk] = fma4(h0, xb[0], acc1[kk]);             \
+                acc0[kk] = fma4(h1, xa[1], acc0[kk]); acc1[kk] = fma4(h1, xb[1], acc1[kk]);             \
             }                                                                                           \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
                 acc0[K] = fma4(sc[u], xa[u], acc0[K]);                                                  \
                 acc1[K] = fma4(sc[u], xb[u], acc1[K]);                                                  \
+            }                                                                                           \
+            /* four rows stay in flight, the vector work is skipped in pairs (a wave runs as many slots */ \
+            /* as its highest-degree row needs, and VALU time is MFMA time on this part)                */ \
+            if (cnt > U0 + 2) {                                                                         \
+                _Pragma("unroll") for (int kk = 0; kk < (GV == 8 ? 1 : K); ++kk) {                      \
+                    const float h2 = group8_bcast<U0 + 2>(myh[kk]), h3 = group8_bcast<U0 + 3>(myh[kk]); \
+                    acc0[kk] = fma4(h2, xa[2], acc0[kk]); acc1[kk] = fma4(h2, xb[2], acc1[kk]);         \
+                    acc0[kk] = fma4(h3, xa[3], acc0[kk]); acc1[kk] = fma4(h3, xb[3], acc1[kk]);         \
+                }                                                                                       \
+                _Pragma("unroll") for (int u = 2; u < 4; ++u) {                                         \
+                    acc0[K] = fma4(sc[u], xa[u], acc0[K]);                                              \
+                    acc1[K] = fma4(sc[u], xb[u], acc1[K]);                                              \
+                }                                                                                       \
             }                                                                                           \
         }
         QOT_EDGE4(0)
@@ -456,7 +465,10 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                     float4 gr[4];                                                                        \
                     float sc[4];                                                                         \
                     QOT_ADJ_EDGE(U0) QOT_ADJ_EDGE(U0 + 1) QOT_ADJ_EDGE(U0 + 2) QOT_ADJ_EDGE(U0 + 3)      \
-                    QOT_ADJ_FMA(U0) QOT_ADJ_FMA(U0 + 1) QOT_ADJ_FMA(U0 + 2) QOT_ADJ_FMA(U0 + 3)          \
+                    QOT_ADJ_FMA(U0) QOT_ADJ_FMA(U0 + 1)                                                  \
+                    /* four rows stay in flight, but the vector work is skipped in pairs: a wave runs as */ \
+                    /* many slots as its highest-degree row needs, and VALU time is MFMA time here      */ \
+                    if (cnt > U0 + 2) { QOT_ADJ_FMA(U0 + 2) QOT_ADJ_FMA(U0 + 3) }                        \
                 }
                 QOT_ADJ_EDGE4(0)
                 if (cnt > 4) QOT_ADJ_EDGE4(4)
