@@ -103,14 +103,22 @@ __device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx,
             _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
                 ldv<CPL>(x + (int64_t)jj[u] * ldx + cbase, xv[u]);                                       \
             _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                           \
-                float h[4];                                                                              \
-                h[0] = group8_bcast<U0 + 0>(myh[kk], upper); h[1] = group8_bcast<U0 + 1>(myh[kk], upper);  \
-                h[2] = group8_bcast<U0 + 2>(myh[kk], upper); h[3] = group8_bcast<U0 + 3>(myh[kk], upper);  \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u)                                            \
-                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h[u], xv[u][c], acc[kk][c]); \
+                const float h0 = group8_bcast<U0 + 0>(myh[kk]), h1 = group8_bcast<U0 + 1>(myh[kk]);      \
+                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h0, xv[0][c], acc[kk][c]); \
+                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h1, xv[1][c], acc[kk][c]); \
             }                                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                \
                 _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
+            /* four rows stay in flight, the vector work is skipped in pairs (VALU time is MFMA time here) */ \
+            if (cnt > U0 + 2) {                                                                          \
+                _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                       \
+                    const float h2 = group8_bcast<U0 + 2>(myh[kk]), h3 = group8_bcast<U0 + 3>(myh[kk]);  \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h2, xv[2][c], acc[kk][c]); \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h3, xv[3][c], acc[kk][c]); \
+                }                                                                                        \
+                _Pragma("unroll") for (int u = 2; u < 4; ++u)                                            \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
+            }                                                                                            \
         }
         QOT_GEN_EDGE4(0)
         if (cnt > 4) QOT_GEN_EDGE4(4)

@@ -847,7 +847,8 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
                 {                                                                                                 \
                     float4 xr0[4], xr1[4];                                                                        \
                     QOT_GH_LOAD(U0) QOT_GH_LOAD(U0 + 1) QOT_GH_LOAD(U0 + 2) QOT_GH_LOAD(U0 + 3)                   \
-                    QOT_GH_ONE(U0) QOT_GH_ONE(U0 + 1) QOT_GH_ONE(U0 + 2) QOT_GH_ONE(U0 + 3)                       \
+                    QOT_GH_ONE(U0) QOT_GH_ONE(U0 + 1)                                                             \
+                    if (cnt > U0 + 2) { QOT_GH_ONE(U0 + 2) QOT_GH_ONE(U0 + 3) }   /* vector work skipped in pairs */ \
                 }
                 QOT_GH_EDGE4(0)
                 if (cnt > 4) QOT_GH_EDGE4(4)
