@@ -46,9 +46,7 @@ __device__ __forceinline__ void nnconv_gather_tile(
     const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
     const int c0 = 8 * sub;
     const int64_t i = tile0 + il;
-    float4 acc0[K + 1], acc1[K + 1];
-#pragma unroll
-    for (int kk = 0; kk <= K; ++kk) { acc0[kk] = f4zero(); acc1[kk] = f4zero(); }
+    float4 acc0[K + 1], acc1[K + 1];        // written (not accumulated) by the first edge slot: no zero fill per tile
     root0 = f4zero(); root1 = f4zero();
     int beg = 0, end = 0;
     // the row's own loads (mean scale, root row) are issued BEFORE the edge loop: behind it they were one more
@@ -60,34 +58,15 @@ __device__ __forceinline__ void nnconv_gather_tile(
         root0 = ld4(x + i * ldx + c0);
         root1 = ld4(x + i * ldx + c0 + 4);
     }
-    for (int base = beg; base < end; base += 8) {
-        // one edge per lane: indices, edge features, edge-MLP hidden vector
-        const int p = base + sub;
-        int myj = 0;
-        float myh[K], mysc = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
-        if (p < end) {
-            myj = (GV == 7) ? (int)(i ^ (p & 31)) : col[p];
-            const int64_t e = (GV == 7) ? (int64_t)p : (int64_t)eidx[p];
-            float ee[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-            mysc = TRANSPOSE ? invdeg[myj] : 1.0f;
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                float h = b1[kk];
-#pragma unroll
-                for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
-                myh[kk] = fmaxf(h, 0.f) * mysc;
-            }
-        }
-        const int cnt = (end - base < 8) ? end - base : 8;
-        // lanes 0..7 of the group hold edges base..base+7; broadcasts with compile-time source lanes run on
-        // the DPP path (as __shfl with a runtime lane each was a ds_bpermute_b32 round trip: ten per edge)
-        // dead slots (lane p >= end) carry myj = 0, h = 0 and scale = 0 from the prefetch above: their terms vanish
-        // without per-use selects (row 0 times zero)
-#define QOT_EDGE4(U0)                                                                                   \
+    const int own = (i < N) ? (int)i : 0;   // dead edge slots read the destination's own row (times zero)
+    // One batch = up to 8 in-edges of every destination, one edge per lane: indices, edge features, edge-MLP hidden vector
+    // (the mean scale 1/deg of the forward form is folded into it), then two blocks of four slots.  Lanes 0..7 of a group
+    // hold edges base..base+7; broadcasts with compile-time source lanes run on the DPP path (as __shfl with a runtime lane
+    // each was a ds_bpermute_b32 round trip: ten per edge).  Dead slots (lane p >= end) carry h = 0 and scale = 0: their
+    // terms vanish without per-use selects.  FIRST: the batch that every destination runs (also one without in-edges); its
+    // first slot WRITES the accumulators.
+#define QOT_ACC(FIRSTSLOT, H, X, A) ((FIRSTSLOT) ? scale4((H), (X)) : fma4((H), (X), (A)))
+#define QOT_EDGE4(U0, FIRST)                                                                            \
         {                                                                                               \
             float4 xa[4], xb[4];                                                                        \
             float sc[4];                                                                                \
@@ -103,13 +82,14 @@ __device__ __forceinline__ void nnconv_gather_tile(
             }                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < (GV == 8 ? 1 : K); ++kk) {                          \
                 const float h0 = group8_bcast<U0 + 0>(myh[kk]), h1 = group8_bcast<U0 + 1>(myh[kk]);     \
-                acc0[kk] = fma4(h0, xa[0], acc0[kk]); acc1[kk] = fma4(h0, xb[0], acc1[kk]);             \
+                acc0[kk] = QOT_ACC(FIRST, h0, xa[0], acc0[kk]); acc1[kk] = QOT_ACC(FIRST, h0, xb[0], acc1[kk]); \
                 acc0[kk] = fma4(h1, xa[1], acc0[kk]); acc1[kk] = fma4(h1, xb[1], acc1[kk]);             \
             }                                                                                           \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
-                acc0[K] = fma4(sc[u], xa[u], acc0[K]);                                                  \
-                acc1[K] = fma4(sc[u], xb[u], acc1[K]);                                                  \
+            if (GV == 8 && (FIRST)) {                                                                   \
+                _Pragma("unroll") for (int kk = 1; kk < K; ++kk) { acc0[kk] = f4zero(); acc1[kk] = f4zero(); } \
             }                                                                                           \
+            acc0[K] = QOT_ACC(FIRST, sc[0], xa[0], acc0[K]); acc1[K] = QOT_ACC(FIRST, sc[0], xb[0], acc1[K]); \
+            acc0[K] = fma4(sc[1], xa[1], acc0[K]); acc1[K] = fma4(sc[1], xb[1], acc1[K]);               \
             /* four rows stay in flight, the vector work is skipped in pairs (a wave runs as many slots */ \
             /* as its highest-degree row needs, and VALU time is MFMA time on this part)                */ \
             if (cnt > U0 + 2) {                                                                         \
@@ -124,14 +104,34 @@ __device__ __forceinline__ void nnconv_gather_tile(
                 }                                                                                       \
             }                                                                                           \
         }
-        QOT_EDGE4(0)
-        if (cnt > 4) QOT_EDGE4(4)
+#define QOT_FWD_BATCH(FIRST)                                                                            \
+    {                                                                                                   \
+        const int p = base + sub;                                                                       \
+        int myj = own;                                                                                  \
+        float myh[K], mysc = 0.f;                                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;                                 \
+        if (p < end) {                                                                                  \
+            myj = (GV == 7) ? (int)(i ^ (p & 31)) : col[p];                                             \
+            const int64_t e = (GV == 7) ? (int64_t)p : (int64_t)eidx[p];                                \
+            float ee[D];                                                                                \
+            _Pragma("unroll") for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];                        \
+            mysc = TRANSPOSE ? invdeg[myj] : srow;                                                      \
+            _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                          \
+                float h = b1[kk];                                                                       \
+                _Pragma("unroll") for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);       \
+                myh[kk] = fmaxf(h, 0.f) * mysc;                                                         \
+            }                                                                                           \
+        }                                                                                               \
+        const int cnt = (end - base < 8) ? end - base : 8;                                              \
+        QOT_EDGE4(0, FIRST)                                                                             \
+        if (cnt > 4) QOT_EDGE4(4, false)                                                                \
+    }
+    int base = beg;
+    QOT_FWD_BATCH(true)
+    for (base = beg + 8; base < end; base += 8) QOT_FWD_BATCH(false)
+#undef QOT_FWD_BATCH
 #undef QOT_EDGE4
-    }
-    if (!TRANSPOSE) {
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk) { acc0[kk] = scale4(srow, acc0[kk]); acc1[kk] = scale4(srow, acc1[kk]); }
-    }
+#undef QOT_ACC
     float4* At4 = reinterpret_cast<float4*>(At);
 #pragma unroll
     for (int kk = 0; kk <= K; ++kk) {       // channels c0+{0,2,4,6} -> hi 0 ; c0+{1,3,5,7} -> hi 1
