@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
             if (j < N) { beg = rowptr_t[j]; end = rowptr_t[j + 1]; acc[K + 1] = ld4(g + j * ldg + c0); }
             for (int base = beg; base < end; base += 16) {
                 const int p = base + sub;
-                int myi = 0;
+                int myi = (int)j;          // dead slots read the node's own g row (times zero), never another node's
                 float myh[K], mysc = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
                         myh[kk] = fmaxf(h, 0.f) * mysc;
                     }
                 }
-                // lanes 0..15 of the row hold out-edges base..base+15 (zeros past the end: a dead slot multiplies row 0
-                // by 0); broadcasts with compile-time source lanes are one DPP move each (row_newbcast) -- with a runtime
+                // lanes 0..15 of the row hold out-edges base..base+15 (zeros past the end: a dead slot multiplies the node's
+                // own row by 0); broadcasts with compile-time source lanes are one DPP move each (row_newbcast) -- with a runtime
                 // lane (__shfl) every one of the ten per edge was a ds_bpermute_b32 + s_waitcnt round trip
                 const int cnt = (end - base < 16) ? end - base : 16;
 #define QOT_ADJ_EDGE(U)                                                                                  \

@@ -90,6 +90,20 @@ def test_topological_given_x(cuda_device):
     assert rel_err(hip(batch.to(cuda_device)), ref(batch)) <= TOL
 
 
+@pytest.mark.parametrize("H", [64, 128])
+def test_non_finite_node_feature_stays_in_its_graph(cuda_device, H):
+    """Edge slots past a destination's degree multiply a row by zero; that row is the destination's OWN row, never a
+    fixed one: a NaN in node 0's features reaches graph 0 only (with row 0 as the filler it reached every destination whose
+    degree is not a multiple of the slot block, i.e. every graph)."""
+    from gnn_qot_estimation_amd import synthetic as S
+    batch = S.topological_batch(2, 5, n=20, e=60)
+    batch.x = torch.randn(batch.num_nodes, H)
+    batch.x[0, 3] = float("nan")
+    _, hip = _models("topo", cuda_device, num_nodes=20, hidden_channels=H, out_channels=3, edge_dim=4, dropout_p=0.0)
+    out = hip.eval()(batch.to(cuda_device))
+    assert bool(torch.isnan(out[0]).any()) and bool(torch.isfinite(out[1:]).all())
+
+
 @pytest.mark.parametrize("B,C,train", [(64, 32, True), (64, 32, False), (17, 128, True), (5, 8, True)])
 def test_lightpath_fwd_bwd(cuda_device, B, C, train):
     from gnn_qot_estimation_amd import synthetic as S
