@@ -418,66 +418,72 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
             const int sub = threadIdx.x & 15, il = threadIdx.x >> 4;
             const int c0 = 4 * sub;
             const int64_t j = tile0 + il;
-            float4 acc[K + 2];
-#pragma unroll
-            for (int kk = 0; kk < K + 2; ++kk) acc[kk] = f4zero();
+            float4 acc[K + 2];          // blocks 0..K are WRITTEN by the first edge slot: no zero fill per tile
+            acc[K + 1] = f4zero();
             int beg = 0, end = 0;
             if (j < N) { beg = rowptr_t[j]; end = rowptr_t[j + 1]; acc[K + 1] = ld4(g + j * ldg + c0); }
-            for (int base = beg; base < end; base += 16) {
-                const int p = base + sub;
-                int myi = (int)j;          // dead slots read the node's own g row (times zero), never another node's
-                float myh[K], mysc = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
-                if (p < end) {
-                    myi = (VARIANT == 7) ? (int)(j ^ (p & 31)) : col_t[p];      // 7: no index chain (arithmetic ids)
-                    const int64_t e = (VARIANT == 7) ? (int64_t)p : (int64_t)eid_t[p];
-                    float ee[D];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-                    mysc = (VARIANT == 7) ? 0.25f : invdeg[myi];
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk) {
-                        float h = b1[kk];
-#pragma unroll
-                        for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
-                        myh[kk] = fmaxf(h, 0.f) * mysc;
-                    }
-                }
-                // lanes 0..15 of the row hold out-edges base..base+15 (zeros past the end: a dead slot multiplies the node's
-                // own row by 0); broadcasts with compile-time source lanes are one DPP move each (row_newbcast) -- with a runtime
-                // lane (__shfl) every one of the ten per edge was a ds_bpermute_b32 + s_waitcnt round trip
-                const int cnt = (end - base < 16) ? end - base : 16;
+            const int own = (j < N) ? (int)j : 0;   // dead slots read the node's own g row (times zero), never another node's
+            // One batch = up to 16 out-edges of every node, one edge per lane of the row (zeros past the end); broadcasts with
+            // compile-time source lanes are one DPP move each (row_newbcast) -- with a runtime lane (__shfl) every one of the
+            // ten per edge was a ds_bpermute_b32 + s_waitcnt round trip.  FIRST: the batch every node runs (also one without
+            // out-edges); its first slot writes the accumulators.
 #define QOT_ADJ_EDGE(U)                                                                                  \
                 {                                                                                        \
                     const int64_t i = (VARIANT == 1) ? (int64_t)(row16_bcast<U>(myi) & 1) : (int64_t)row16_bcast<U>(myi); \
                     gr[(U) & 3] = ld4(g + i * ldg + c0);                                                 \
                     sc[(U) & 3] = row16_bcast<U>(mysc);                                                  \
                 }
-#define QOT_ADJ_FMA(U)                                                                                   \
+#define QOT_ADJ_FMA(U, FIRSTSLOT)                                                                        \
                 {                                                                                        \
                     _Pragma("unroll") for (int kk = 0; kk < (VARIANT == 6 ? 1 : K); ++kk)                \
-                        acc[kk] = fma4(row16_bcast<U>(myh[kk]), gr[(U) & 3], acc[kk]);                   \
-                    acc[K] = fma4(sc[(U) & 3], gr[(U) & 3], acc[K]);                                     \
+                        acc[kk] = (FIRSTSLOT) ? scale4(row16_bcast<U>(myh[kk]), gr[(U) & 3])             \
+                                              : fma4(row16_bcast<U>(myh[kk]), gr[(U) & 3], acc[kk]);     \
+                    if (VARIANT == 6 && (FIRSTSLOT)) {                                                   \
+                        _Pragma("unroll") for (int kk = 1; kk < K; ++kk) acc[kk] = f4zero();             \
+                    }                                                                                    \
+                    acc[K] = (FIRSTSLOT) ? scale4(sc[(U) & 3], gr[(U) & 3]) : fma4(sc[(U) & 3], gr[(U) & 3], acc[K]); \
                 }
-#define QOT_ADJ_EDGE4(U0)                                                                                \
+#define QOT_ADJ_EDGE4(U0, FIRST)                                                                         \
                 {                                                                                        \
                     float4 gr[4];                                                                        \
                     float sc[4];                                                                         \
                     QOT_ADJ_EDGE(U0) QOT_ADJ_EDGE(U0 + 1) QOT_ADJ_EDGE(U0 + 2) QOT_ADJ_EDGE(U0 + 3)      \
-                    QOT_ADJ_FMA(U0) QOT_ADJ_FMA(U0 + 1)                                                  \
+                    QOT_ADJ_FMA(U0, FIRST) QOT_ADJ_FMA(U0 + 1, false)                                    \
                     /* four rows stay in flight, but the vector work is skipped in pairs: a wave runs as */ \
                     /* many slots as its highest-degree row needs, and VALU time is MFMA time here      */ \
-                    if (cnt > U0 + 2) { QOT_ADJ_FMA(U0 + 2) QOT_ADJ_FMA(U0 + 3) }                        \
+                    if (cnt > U0 + 2) { QOT_ADJ_FMA(U0 + 2, false) QOT_ADJ_FMA(U0 + 3, false) }          \
                 }
-                QOT_ADJ_EDGE4(0)
-                if (cnt > 4) QOT_ADJ_EDGE4(4)
-                if (cnt > 8) QOT_ADJ_EDGE4(8)
-                if (cnt > 12) QOT_ADJ_EDGE4(12)
+#define QOT_ADJ_BATCH(FIRST)                                                                             \
+            {                                                                                            \
+                const int p = base + sub;                                                                \
+                int myi = own;                                                                           \
+                float myh[K], mysc = 0.f;                                                                \
+                _Pragma("unroll") for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;                          \
+                if (p < end) {                                                                           \
+                    myi = (VARIANT == 7) ? (int)(j ^ (p & 31)) : col_t[p];      /* 7: arithmetic ids */  \
+                    const int64_t e = (VARIANT == 7) ? (int64_t)p : (int64_t)eid_t[p];                   \
+                    float ee[D];                                                                         \
+                    _Pragma("unroll") for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];                 \
+                    mysc = (VARIANT == 7) ? 0.25f : invdeg[myi];                                         \
+                    _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                   \
+                        float h = b1[kk];                                                                \
+                        _Pragma("unroll") for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h); \
+                        myh[kk] = fmaxf(h, 0.f) * mysc;                                                  \
+                    }                                                                                    \
+                }                                                                                        \
+                const int cnt = (end - base < 16) ? end - base : 16;                                     \
+                QOT_ADJ_EDGE4(0, FIRST)                                                                  \
+                if (cnt > 4) QOT_ADJ_EDGE4(4, false)                                                     \
+                if (cnt > 8) QOT_ADJ_EDGE4(8, false)                                                     \
+                if (cnt > 12) QOT_ADJ_EDGE4(12, false)                                                   \
+            }
+            int base = beg;
+            QOT_ADJ_BATCH(true)
+            for (base = beg + 16; base < end; base += 16) QOT_ADJ_BATCH(false)
+#undef QOT_ADJ_BATCH
 #undef QOT_ADJ_EDGE4
 #undef QOT_ADJ_FMA
 #undef QOT_ADJ_EDGE
-            }
             // channels c0..c0+3 of block kk: k = 64 kk + c0 + t -> group 8 kk + sub/2,
             // (r, hi) = (2 (sub&1) + t/2, t&1): two 8-byte stores per block, conflict-free
 #pragma unroll
