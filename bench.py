@@ -342,7 +342,10 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # The part needs ~12 ms of load to reach its clock: whatever W the caller asks for, at least 50
+    # untimed steps (~30 ms) run before the timed region; the extra ones are reported as config.prime_steps.
+    prime_steps = max(0, 50 - args.warmup)
+    for _ in range(prime_steps + args.warmup):
         step()
     barrier()
     torch.cuda.synchronize()
@@ -379,7 +382,7 @@ def main():
                                    "SGD momentum 0.9, SmoothL1; " + ("graph index cached across steps (BENCH_PREP_OUTSIDE: the HBM-resident, cached-batch loader mode; not the headline)" if os.environ.get("BENCH_PREP_OUTSIDE") else "CSR build included in every step"),
                        "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world,
                        "launch": "eager" if step.graph_fb is None else "hip-graph replay (fwd+bwd, optimizer)",
-                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "parallelism": f"dp{world}", "final_loss": loss, "prime_steps": prime_steps,
                        "collective_world_size": dist.get_world_size() if world > 1 else 1,
                        "collective_backend": dist.get_backend() if world > 1 else None,
                        "all_reduce_us": all_reduce_us,
