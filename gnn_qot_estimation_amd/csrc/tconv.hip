@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256) void tconv_bwd_dst_kernel(
             for (int c = 0; c < CPL; ++c)
 #pragma unroll
                 for (int dd = 0; dd < DCH; ++dd)
-                    if (d0 + dd < D) wred[rloc * H * DCH + (c0 + c) * DCH + dd] = wc[c][d0 + dd];
-            __syncthreads();
+                    if (d0 + dd < D) wred[rloc * H * DCH + dd * H + c0 + c] = wc[c][d0 + dd];   // [row][feature][channel]: lanes
+            __syncthreads();                                                                  // write consecutive 16-B pieces
             for (int o = threadIdx.x; o < H * dc; o += 256) {
-                const int ch = o / dc, dd = o % dc;
+                const int dd = o / H, ch = o % H;
                 float sacc = 0.f;
-                for (int r = 0; r < RPB; ++r) sacc += wred[r * H * DCH + ch * DCH + dd];
+                for (int r = 0; r < RPB; ++r) sacc += wred[r * H * DCH + dd * H + ch];
                 wedge_partials[(int64_t)blockIdx.x * H * D + ch * D + d0 + dd] = sacc;
             }
         }
