@@ -25,7 +25,7 @@ def t(iters=20):
     en.record(); torch.cuda.synchronize(); return st.elapsed_time(en) / iters * 1e3
 names = {0: "full", 1: "mfma only (no gather)", 2: "gather only (no mfma)", 100: "full, 1 WG/CU", 101: "mfma only, 1 WG/CU",
          102: "gather only, 1 WG/CU", 4: "mfma only, B not streamed", 5: "mfma only, no A reads, no B", 104: "mfma only, B not streamed, 1 WG/CU",
-         105: "mfma only, no A no B, 1 WG/CU", 6: "full, gathered rows hot", 7: "full, no index chain", 8: "full, one of K sums"}
+         105: "mfma only, no A no B, 1 WG/CU", 6: "full, gathered rows hot", 7: "full, no index chain", 8: "full, one of K sums", 10: "cost shape of a rank-1 MFMA gather (4 edges / destination, no control flow)"}
 res = {v: [] for v in names}
 for rnd in range(5):
     for v in names:
