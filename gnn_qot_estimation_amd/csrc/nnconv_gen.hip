@@ -231,20 +231,24 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
                 for (int kk = 0; kk <= K; ++kk) frag_store<CW, CPL>(At, kk, sub, il, acc[kk]);
                 if (ROOT_LDS) frag_store<CW, CPL>(At, K + 1, sub, il, root);
             }
-            __syncthreads();
 #ifdef QOT_DIAG
-            if (variant == 3) { lds_barrier(); continue; }
             const int64_t gstep = (variant == 2 || variant == 4) ? 0 : 1;      // 0: every fragment load hits the same line
 #else
             constexpr int64_t gstep = 1;
 #endif
-            // ---- main part: this wave's groups [ks*GS, (ks+1)*GS) against its column blocks
+            // ---- main part: this wave's groups [ks*GS, (ks+1)*GS) against its column blocks.  The first chunk of weight
+            // fragments is requested in FRONT of the barrier that publishes the operand tile, and that barrier orders LDS
+            // traffic only: behind a __syncthreads() their L2 round trip was exposed once per pass.
             const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)(p * NCB + cb0) * GALL + ks * GS) * 64 + lane;
             float4 bc[CBW][CH], bn[CBW][CH];
 #pragma unroll
             for (int q = 0; q < CBW; ++q)
 #pragma unroll
                 for (int u = 0; u < CH; ++u) bc[q][u] = wp[((int64_t)q * GALL + u) * 64 * gstep];
+            lds_barrier();
+#ifdef QOT_DIAG
+            if (variant == 3) { lds_barrier(); continue; }
+#endif
             int ch = 0;
 #pragma unroll 1
             for (; ch + 1 < NCH; ch += 2) {
