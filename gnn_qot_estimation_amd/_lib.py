@@ -172,7 +172,16 @@ def check(code: int, what: str):
 
 
 def call(name: str, *args):
-    """Invoke ``name`` with the current stream appended; raise on a non-zero status."""
-    code = getattr(_lib or load(), name)(*args, stream())
+    """Invoke ``name`` with the current stream appended; raise on a non-zero status.
+
+    Arguments may be tensors: they are passed as their device pointers and stay referenced by ``args`` until the
+    launch has been enqueued, so ``call(name, t.contiguous(), ...)`` is safe where ``call(name, ptr(t.contiguous()),
+    ...)`` is NOT (``ptr`` returns a bare int: the temporary dies at once and the caching allocator may hand its
+    block to the next temporary of the same statement -- the round-2 GPU fault)."""
+    if any(isinstance(a, torch.Tensor) for a in args):
+        raw = tuple(a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args)
+    else:
+        raw = args
+    code = getattr(_lib or load(), name)(*raw, stream())
     if code != 0:
         check(code, name)

@@ -107,7 +107,9 @@ class Batch(Data):
 def balanced_ranges(weights, world: int):
     """``world`` contiguous ranges ``[lo, hi)`` over ``len(weights)`` items whose weight sums are as even as contiguity
     allows: boundary k is the first prefix reaching ``k/world`` of the total.  Deterministic, every rank computes the
-    same cuts from the same counts; a range may be empty."""
+    same cuts from the same counts.  With at least ``world`` items every range holds at least one (a rank with an empty
+    share makes ``harness.run_epoch`` skip the whole global batch of a model with synchronised BatchNorm); with fewer
+    items the trailing ranges are empty."""
     w = torch.as_tensor(weights, dtype=torch.float64).reshape(-1).cpu()
     n = w.numel()
     if n == 0:
@@ -124,8 +126,10 @@ def balanced_ranges(weights, world: int):
         below = float(csum[i - 1]) if i > 0 else 0.0
         cuts.append(i + 1 if (float(csum[i]) - t) <= (t - below) else i)  # include item i when that lands closer
     cuts = [0] + [min(max(c, 0), n) for c in cuts] + [n]
-    for k in range(1, len(cuts)):
-        cuts[k] = max(cuts[k], cuts[k - 1])
+    for k in range(1, world):
+        lo = cuts[k - 1] + 1 if n >= world else cuts[k - 1]        # n >= world: nobody goes empty-handed ...
+        hi = n - (world - k) if n >= world else n                   # ... and enough items stay for the ranks behind
+        cuts[k] = min(max(cuts[k], lo), hi)
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 

@@ -23,28 +23,25 @@ import torch.distributed as dist
 _REDUCE_MODE = {}
 
 
-def _probe_avg(like: torch.Tensor, group=None) -> int:
-    if not (like.is_cuda and dist.get_backend(group) == "nccl"):
+def _avg_capable(like: torch.Tensor, group=None) -> int:
+    """1 when this rank's backend runs ``ReduceOp.AVG`` on tensors like ``like``: the nccl (= RCCL) backend on device
+    tensors (``ncclAvg``, NCCL >= 2.10 -- every RCCL that ships with ROCm 5+); gloo has no AVG.  A LOCAL capability
+    test: no collective is issued here.  (Round 2 probed by issuing a real AVG all-reduce inside try/except: a rank
+    whose backend rejected the op would have left the accepting ranks waiting in a collective it never joined.)"""
+    if not like.is_cuda or not hasattr(dist.ReduceOp, "AVG"):
         return 0
-    try:
-        probe = torch.ones(1, dtype=like.dtype, device=like.device)
-        dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
-        return 1
-    except (RuntimeError, ValueError):
-        return 0
+    return 1 if dist.get_backend(group) == "nccl" else 0
 
 
 def reduce_mode(like: torch.Tensor, group=None) -> str:
     """``"avg"`` when every rank of ``group`` can run ``ReduceOp.AVG`` on tensors like ``like`` (RCCL), else
-    ``"sum"`` (gloo has no AVG: sum, then divide).  Decided once per (group, device type): each rank probes the
-    op on a scratch tensor -- a backend that rejects it does so when the call is enqueued, before anything is
-    exchanged -- and the outcomes are combined with a MIN all-reduce, so all ranks agree even if one build
-    differs.  The AVG branch is unverified at world > 1 until a multi-GPU run exists."""
+    ``"sum"`` (sum, then divide).  Decided once per (group, device type): each rank evaluates a local capability flag
+    and the flags are combined with ONE MIN all-reduce (an op every backend has), so all ranks take the same branch
+    on every later step even if one build differs."""
     key = (id(group) if group is not None else 0, like.device.type)
     mode = _REDUCE_MODE.get(key)
     if mode is None:
-        ok = _probe_avg(like, group)
-        flag = torch.tensor([ok], dtype=torch.int32, device=like.device)
+        flag = torch.tensor([_avg_capable(like, group)], dtype=torch.int32, device=like.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         mode = _REDUCE_MODE[key] = "avg" if int(flag.item()) == 1 else "sum"
     return mode
@@ -97,13 +94,17 @@ class FlatModel:
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
             off += n
 
-    def all_reduce_grads(self, weight: Optional[torch.Tensor] = None, group=None):
+    def all_reduce_grads(self, weight: Optional[torch.Tensor] = None, group=None, force: bool = False):
         """Average gradients over ranks.  ``weight`` (0-dim tensor, e.g. the local number of
         loss rows) gives a weighted mean: needed where shards contribute different counts
         (LightpathGNN: n_lut differs per shard, cf. lightpath_training/train.py:133).  Weighting after
         backward is exact only when ranks are independent inside backward; with synchronised
-        BatchNorm statistics scale the local loss with ``loss_scale`` instead and average plainly."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        BatchNorm statistics scale the local loss with ``loss_scale`` instead and average plainly.
+        ``force``: issue the collective even in a single-rank group (where it is the identity) -- how the one-GPU box
+        exercises the RCCL call itself (``tests/test_gpu_dp.py``)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(group) == 1 and not force:
             return
         world = dist.get_world_size(group)
         if weight is None:

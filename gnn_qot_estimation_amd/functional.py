@@ -478,8 +478,13 @@ class NNConvFn(torch.autograd.Function):
             raise _lib.QotError("NNConv HIP path needs in_channels == out_channels")
         if hin != 64 and hin not in GEN_WIDTHS:
             raise _lib.QotError(f"NNConv HIP path: hidden width {hin} not in (16, 32, 64, 128, 256)")
+        if D > 8:
+            raise _lib.QotError("NNConv HIP path: edge_dim <= 8 (include/qot_gnn.h)")
         if D > 4:
-            raise _lib.QotError("NNConv HIP path: edge_dim <= 4")
+            # edge_dim 5..8 (the reference takes edge_dim = len(dataset.FEATURES), topological_training/dataset.py:40):
+            # the fused tile kernels are built for K = 2D <= 8 operand blocks; wider edge MLPs materialise the operand
+            # A [N, (K+2)H] (qot_nnconv_agg) and multiply it with library GEMMs -- correct at every width, slower
+            return NNConvFn._forward_wide_edge(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph, act, side)
         # (Wcat, WcatT, Wk^T) in MFMA fragment order; every width runs gather -> LDS tile -> fp32 MFMA, the operand
         # [N, (K+2)H] never exists in HBM
         if hin == 64:
@@ -489,13 +494,58 @@ class NNConvFn(torch.autograd.Function):
         out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
         _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                   P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
-        A = None
-        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, wp_adj, bp, out if act is not None else None,
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, None, wp_adj, bp, out if act is not None else None,
                               act[3] if act is not None else None)
         ctx.graph = graph
         ctx.act = None if act is None else (act[0], act[1], act[2])
         ctx.side = side if act is not None else None
         return out
+
+    @staticmethod
+    def _forward_wide_edge(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph, act, side):
+        N, hin = x.shape
+        hout = wroot.shape[0]
+        K, D = w1.shape
+        A = torch.empty(N, (K + 2) * hin, dtype=torch.float32, device=x.device)
+        _lib.call("qot_nnconv_agg", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
+                  P(graph.eid), None, P(graph.invdeg), 0, P(A), N, hin, D)
+        out = torch.addmm(bias, A, nnconv_wcat(w2, b2, wroot, hin, hout, K))
+        if act is not None:                  # separate activation kernel, same mask as the fused epilogue
+            pre = out
+            out = torch.empty_like(pre)
+            _lib.call("qot_act_fwd", P(pre), P(out), pre.numel(), *_act_args(act)[1:])
+        ctx.save_for_backward(x, edge_attr, w1, b1, w2, b2, wroot, A, None, None, out if act is not None else None,
+                              act[3] if act is not None else None)
+        ctx.graph = graph
+        ctx.act = None if act is None else (act[0], act[1], act[2])
+        ctx.side = side if act is not None else None
+        return out
+
+    @staticmethod
+    def _backward_wide_edge(ctx, g, gbias):
+        x, edge_attr, w1, b1, w2, b2, wroot, A, _, _, _, _ = ctx.saved_tensors
+        graph = ctx.graph
+        N, hin = x.shape
+        hout = wroot.shape[0]
+        K, D = w1.shape
+        dev = x.device
+        gwcat = gemm_tn(A, g)                                # [(K+2)Hin, Hout] = A^T g
+        gx = None
+        if ctx.needs_input_grad[0]:
+            U = torch.empty(N, (K + 2) * hout, dtype=torch.float32, device=dev)
+            _lib.call("qot_nnconv_agg", P(g), hout, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t), P(graph.col_t),
+                      P(graph.pos_t), P(graph.eid), P(graph.invdeg), 1, P(U), N, hout, D)
+            gx = U @ nnconv_wcat_t(w2, b2, wroot, hin, hout, K)
+        gw2 = gwcat[:K * hin].view(K, hin, hout).permute(1, 2, 0).reshape(hin * hout, K)
+        gb2 = gwcat[K * hin:(K + 1) * hin].reshape(hin * hout)
+        gwroot = gwcat[(K + 1) * hin:].t()
+        wk = w2.view(hin, hout, K).permute(2, 0, 1).reshape(K * hin, hout)
+        GA = (g @ wk.t()).contiguous()                       # [N, K*Hin]
+        gw1 = torch.zeros(K, D, dtype=torch.float32, device=dev)
+        gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
+        _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
+                  P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
 
     @staticmethod
     def backward(ctx, g):
@@ -516,6 +566,8 @@ class NNConvFn(torch.autograd.Function):
             g, gbias = act_backward_colsum(g, y, ctx.act + (act_step,))
         else:
             gbias = colsum(g)
+        if A is not None:
+            return NNConvFn._backward_wide_edge(ctx, g, gbias)
         N, hin = x.shape
         hout = wroot.shape[0]
         K, D = w1.shape

@@ -46,6 +46,45 @@ def require_cuda(*tensors):
             )
 
 
+_STATUS = {}
+# Every eager per-graph index build reads its status word back (one 4-byte host read, ~30 us).  A pipelined loader
+# loop that must not synchronise per batch may set this False and call ``check_index_status(device)`` once per epoch.
+CHECK_INDEX_STATUS = True
+
+
+def _index_status(dev) -> torch.Tensor:
+    """Per-device int32 flag word of ``qot_csr_build_by_graph`` (bit 0: an edge leaves its graph's node range, bit 1: a
+    slice lies outside the arrays or exceeds the stated maximum).  Zeroed once and sticky: the kernel only ORs into
+    it, so no fill launch rides in a captured step."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _STATUS.get(key)
+    if st is None:
+        st = _STATUS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return st
+
+
+def check_index_status(dev) -> None:
+    """Raise if a per-graph index build on ``dev`` flagged its slices (the kernel then wrote nothing for that graph).
+    One 4-byte host read; skipped while a stream capture is running (a captured step has been through an eager step
+    with the same batch object, and the flag is sticky: the next eager build or an explicit call reports it)."""
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:
+        pass
+    st = _index_status(dev)
+    code = int(st.item())
+    if code:
+        st.zero_()
+        what = []
+        if code & 1:
+            what.append("an edge leaves its graph's node range")
+        if code & 2:
+            what.append("a graph slice lies outside the node / edge arrays or exceeds (max_nodes, max_edges)")
+        raise _lib.QotError("qot_csr_build_by_graph: inconsistent batch slices (" + "; ".join(what) + "): ptr / edge_ptr "
+                            "do not describe edge_index -- pass slices=None for the general build")
+
+
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False,
                       slices=None, node_ids: Optional[torch.Tensor] = None) -> GraphIndex:
     """``slices = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 device tensors ``[B+1]`` and host
@@ -82,11 +121,17 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
                 ids = node_ids.contiguous()
                 g.ids32 = torch.empty(N, **i32)
                 g.colf, g.colf_t = torch.empty(max(E, 1), **i32), torch.empty(max(E, 1), **i32)
-            _lib.call("qot_csr_build_by_graph", _lib.ptr(ei), E, N, _lib.ptr(node_ptr.contiguous()),
-                      _lib.ptr(edge_ptr.contiguous()), B, int(max_n), int(max_m), _lib.ptr(g.rowptr), _lib.ptr(g.col),
-                      _lib.ptr(g.eid), _lib.ptr(g.row), _lib.ptr(g.rowptr_t), _lib.ptr(g.col_t), _lib.ptr(g.pos_t),
-                      _lib.ptr(g.eid_t), _lib.ptr(g.invdeg), None, _lib.ptr(ids), _lib.ptr(g.ids32), _lib.ptr(g.colf),
-                      _lib.ptr(g.colf_t), _lib.ptr(g.ptr32))
+            # Named, so that both outlive the launch: `ptr(node_ptr.contiguous()), ptr(edge_ptr.contiguous())` hands the
+            # kernel two pointers into ONE block when the inputs are strided views (the first temporary is freed and its
+            # block reused by the second) -- the round-2 GPU fault, DESIGN.md section 8.  Tensors go to `_lib.call`
+            # as tensors; it takes the pointers itself while its argument tuple keeps them alive.
+            np_c, ep_c = node_ptr.contiguous(), edge_ptr.contiguous()
+            status = _index_status(dev)
+            _lib.call("qot_csr_build_by_graph", ei, E, N, np_c, ep_c, B, int(max_n), int(max_m), g.rowptr, g.col,
+                      g.eid, g.row, g.rowptr_t, g.col_t, g.pos_t, g.eid_t, g.invdeg, status, ids, g.ids32, g.colf,
+                      g.colf_t, g.ptr32)
+            if CHECK_INDEX_STATUS:
+                check_index_status(dev)
             return g
     ws_bytes = lib.qot_csr_workspace_bytes(E, N, int(gat_self_loops))
     if ws_bytes == 0:

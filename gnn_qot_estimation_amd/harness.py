@@ -410,9 +410,27 @@ def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: s
     loader = GraphLoader(dataset, batch_size, shuffle=False, device=device,
                          batches=_local_batches(idx, batch_size, rank, world, _graph_costs(dataset, idx)))
     kept, skipped = [], 0
+    # Under data parallelism a rank sees only its share of every global batch.  The reference decides "no LUT node in the
+    # batch" (lightpath_training/test.py:82-85) on the WHOLE batch, so a share without LUT rows contributes zero rows
+    # (allow_empty_lut) and the skip is decided afterwards from the row counts of all ranks, per global batch.
+    sharded_lut = world > 1 and kind == "lightpath" and hasattr(model, "allow_empty_lut")
+    shares = []                                        # (global batch, rows this rank produced, graphs in its share)
     with torch.no_grad():
         for b, data in enumerate(loader):
             if data is None:
+                continue
+            if sharded_lut:
+                model.allow_empty_lut = True
+                try:
+                    out, y = fwd(model, data, output_dim)
+                finally:
+                    model.allow_empty_lut = False
+                shares.append((b, int(y.shape[0]), int(data.num_graphs)))
+                if y.shape[0] == 0:
+                    continue
+                stats.update(y, out)
+                if return_predictions:
+                    kept.append((b, y.detach().clone(), out.detach().clone()))
                 continue
             try:
                 out, y = fwd(model, data, output_dim)
@@ -422,6 +440,16 @@ def evaluate(model, dataset, indices: Optional[Sequence[int]] = None, *, kind: s
             stats.update(y, out)
             if return_predictions:
                 kept.append((b, y.detach().clone(), out.detach().clone()))
+    if sharded_lut:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, shares)
+        rows, graphs = {}, {}
+        for per_rank in everyone:
+            for b, r, g in per_rank:
+                rows[b] = rows.get(b, 0) + r
+                graphs[b] = graphs.get(b, 0) + g
+        dead = {b for b, r in rows.items() if r == 0}  # global batches without any LUT node: skipped as a whole
+        skipped = sum(g for b, r, g in shares if b in dead)
     stats.all_reduce()
     keys = list(output_keys)[:output_dim]
     scale = torch.tensor([target_ranges[k]["max"] - target_ranges[k]["min"] for k in keys], dtype=torch.float64)

@@ -82,6 +82,12 @@ class LightpathGNN(nn.Module):
         return out
 
     def forward(self, data):
+        if not self.conv1.bias.is_cuda:
+            # a model left on the CPU: opt-in upload (QOT_AUTO_DEVICE=1), or a loud error -- never a CPU computation
+            from . import auto_device
+            if auto_device.enabled():
+                return auto_device.forward(self, data)
+            raise auto_device.cpu_model_error()
         if self._qot_cp is not None:
             return self._forward_padded(data)
         x, edge_index, batch = data.x, data.edge_index, data.batch

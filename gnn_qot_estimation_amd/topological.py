@@ -108,6 +108,12 @@ class TopologicalGNN(nn.Module):
         return torch.func.functional_call(shadow, padded.topological_params(self, self._qot_hp), (data,))
 
     def forward(self, data):
+        if not self.node_embeddings.weight.is_cuda:
+            # a model left on the CPU (the reference's topological_training/train.py:62): opt-in upload, or a loud error
+            from . import auto_device
+            if auto_device.enabled():
+                return auto_device.forward(self, data)
+            raise auto_device.cpu_model_error()
         if self._qot_hp is not None:
             return self._forward_padded(data)
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr

@@ -30,8 +30,12 @@
  *   - Indices inside the library are int32 (N, E < 2^31); the int64 edge_index of the
  *     reference contract is consumed only by qot_csr_build.
  *   - Supported widths: H (and heads*C) power of two in [16, 256] (heads*C up to 1024),
- *     edge_dim D in {1..8}.  Anything else returns QOT_ERR_UNSUPPORTED (callers must fail
- *     loudly; there is no CPU fallback).
+ *     edge_dim D in {1..8} for TransformerConv and for the NNConv building blocks qot_nnconv_agg /
+ *     qot_nnconv_bwd_edge; the FUSED NNConv tile kernels (qot_nnconv_fused, qot_nnconv_adjoint_dw,
+ *     qot_nnconv_gradh_fused, qot_nnconv_dw) are built for D <= 4 (K = 2D <= 8 operand blocks per LDS tile)
+ *     and return QOT_ERR_UNSUPPORTED above it -- the host side (functional.NNConvFn) then runs
+ *     {qot_nnconv_agg, GEMM, qot_nnconv_bwd_edge}.  Anything else returns QOT_ERR_UNSUPPORTED (callers must
+ *     fail loudly; there is no CPU fallback).
  */
 #ifndef QOT_GNN_H
 #define QOT_GNN_H

@@ -94,6 +94,22 @@ def test_hip_path_refuses_cpu_tensors():
         lp(S.lightpath_batch(2))
 
 
+def test_cpu_model_error_names_the_opt_in_and_the_opt_in_never_computes_on_cpu(monkeypatch):
+    """configs[0] / the reference's ``topological_training/train.py:62`` (device pinned to CPU): the default is a loud
+    error that names ``QOT_AUTO_DEVICE``; with the switch set and no GPU visible it is still an error -- the switch
+    uploads to the GPU, it is not a CPU path."""
+    m = q.TopologicalGNN(14, 32, 3, 4)
+    monkeypatch.delenv("QOT_AUTO_DEVICE", raising=False)
+    with pytest.raises(_lib.QotError, match="QOT_AUTO_DEVICE=1"):
+        m(S.topological_batch(1, 2))
+    if not torch.cuda.is_available():
+        monkeypatch.setenv("QOT_AUTO_DEVICE", "1")
+        with pytest.raises(_lib.QotError, match="no GPU is visible"):
+            m(S.topological_batch(1, 2))
+        with pytest.raises(_lib.QotError, match="no GPU is visible"):
+            q.LightpathGNN(5, 8, 3, 1)(S.lightpath_batch(2))
+
+
 def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         q.TransformerConv(8, 8, heads=2, edge_dim=4)

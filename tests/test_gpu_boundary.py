@@ -1,0 +1,94 @@
+"""The reference's train-step body, VERBATIM, on a model its script leaves on the CPU (``QOT_AUTO_DEVICE=1``).
+
+``/root/reference/topological_training/train.py:62`` pins ``device = torch.device("cpu")``; ``:63`` ``model.to(device)``,
+``:66`` ``optim.SGD(model.parameters(), lr=0.1, momentum=0.9)``, ``:69`` ``nn.SmoothL1Loss()``, and the step body
+``:108-116`` is ``data = data.to(device); optimizer.zero_grad(); out = model(data); loss = criterion(out,
+data.y.view(-1, 3)); loss.backward(); optimizer.step()``.  BASELINE.json ``configs[0]`` is that script at 14 nodes,
+hidden 32, batch 16.  The same lines run here against the HIP modules (parameters, optimizer state and loss stay on the
+CPU; forward/backward run on the GPU kernels) and against the oracle; parameters after three steps must agree.
+"""
+import pytest
+import torch
+from torch import nn, optim
+
+from helpers import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_step_body(model, loader, device, criterion, optimizer):
+    # topological_training/train.py:107-116, line for line (tqdm dropped)
+    total_loss = 0
+    for data in loader:
+        data = data.to(device)
+        optimizer.zero_grad()
+        out = model(data)
+        loss = criterion(out, data.y.view(-1, 3))
+        loss.backward()
+        optimizer.step()
+        total_loss += loss.item()
+    return total_loss
+
+
+def test_reference_topological_step_body_on_a_cpu_constructed_model(cuda_device, monkeypatch):
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import _lib, synthetic as S
+    from oracle import sparse as O
+    device = torch.device("cpu")                     # train.py:62
+    torch.manual_seed(0)
+    ref = O.TopologicalGNN(14, 32, 3, 4, dropout_p=0.0)
+    hip = q.TopologicalGNN(14, 32, 3, 4, dropout_p=0.0)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    ref.to(device), hip.to(device)                   # train.py:63
+    loader = [S.topological_batch(1, 16), S.topological_batch(1, 16, first_graph=16), S.topological_batch(1, 16)]
+    monkeypatch.delenv("QOT_AUTO_DEVICE", raising=False)
+    with pytest.raises(_lib.QotError, match="QOT_AUTO_DEVICE=1"):
+        hip(loader[0])
+    monkeypatch.setenv("QOT_AUTO_DEVICE", "1")
+    losses = []
+    for m in (ref, hip):
+        m.train()
+        opt = optim.SGD(m.parameters(), lr=0.1, momentum=0.9)       # train.py:66
+        losses.append(_reference_step_body(m, loader, device, nn.SmoothL1Loss(), opt))
+    assert abs(losses[0] - losses[1]) <= 1e-4 * abs(losses[0])
+    for (k, a), (_, b) in zip(ref.state_dict().items(), hip.state_dict().items()):
+        assert not b.is_cuda, k                                     # the caller's parameters never moved
+        assert rel_err(b, a) <= 10 * TOL, (k, rel_err(b, a))        # three SGD steps compound the 1e-4 bar
+    out = hip.eval()(loader[0])
+    assert not out.is_cuda and rel_err(out, ref.eval()(loader[0])) <= 10 * TOL
+    # the weights the script would save load into a GPU-resident model unchanged
+    gpu = q.TopologicalGNN(14, 32, 3, 4, dropout_p=0.0)
+    gpu.load_state_dict(hip.state_dict(), strict=True)
+    assert rel_err(gpu.to(cuda_device).eval()(loader[0].to(cuda_device)).cpu(), out) <= TOL
+
+
+def test_reference_lightpath_step_on_a_cpu_constructed_model_keeps_running_statistics(cuda_device, monkeypatch):
+    """lightpath_training/train.py:111-132 shape of the step (forward returns (out, lut_batch); BatchNorm buffers are the
+    caller's): running statistics and ``num_batches_tracked`` move on the CPU module as they do in the oracle."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    from oracle import sparse as O
+    monkeypatch.setenv("QOT_AUTO_DEVICE", "1")
+    torch.manual_seed(0)
+    ref = O.LightpathGNN(5, 32, 3, 1, dropout_p=0.0)
+    hip = q.LightpathGNN(5, 32, 3, 1, dropout_p=0.0)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    batches = [S.lightpath_batch(24), S.lightpath_batch(24, first_graph=24)]
+    crit = nn.SmoothL1Loss()
+    for m in (ref, hip):
+        m.train()
+        opt = optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+        for data in batches:
+            data = data.to(torch.device("cpu"))
+            opt.zero_grad()
+            out, lut_batch = m(data)
+            loss = crit(out, data.y[lut_batch])
+            loss.backward()
+            opt.step()
+    sd_r, sd_h = ref.state_dict(), hip.state_dict()
+    assert int(sd_h["norm1.module.num_batches_tracked"]) == int(sd_r["norm1.module.num_batches_tracked"]) == 2
+    for k in sd_r:
+        if sd_r[k].dtype.is_floating_point:
+            assert not sd_h[k].is_cuda and rel_err(sd_h[k], sd_r[k]) <= 10 * TOL, k
+    with pytest.raises(ValueError, match="No LUT node found in the batch."):
+        hip(S.lightpath_batch(4, lut=False))

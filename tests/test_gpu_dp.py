@@ -125,13 +125,33 @@ def _lp_epoch(dev, graphs):
     return model, flat, res
 
 
+def _lp_eval(model, dev):
+    """evaluate() over 24 graphs in batches of 4: global batch 1 (graphs 4..7) and 5 (20..23) hold no LUT node at all
+    (skipped as a whole, 8 graphs), every other batch is LUT-carrying on both ranks' shares."""
+    from gnn_qot_estimation_amd import harness as Hn
+    # second dataset: graphs 2..3 LUT-less as well, so that with batch 4 and two ranks rank 1's share of batch 0 is
+    # LUT-less while the GLOBAL batch is not -- per-shard counting (round 2) reported those 2 graphs as skipped
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    graphs = []
+    for g in range(24):
+        b = S.lightpath_batch(1, first_graph=g, lut=not (2 <= g < 8 or 20 <= g < 24))
+        graphs.append(q.Data(x=b.x, edge_index=b.edge_index, y=b.y, num_nodes=b.num_nodes))
+    metrics, y_true, y_pred, skipped = Hn.evaluate(model, graphs, range(24), kind="lightpath", batch_size=4, device=dev,
+                                                   return_predictions=True)
+    return dict(skipped=int(skipped), rows=int(y_true.shape[0]), y_pred=y_pred.clone(),
+                r2=[metrics[k]["R2"] for k in ("OSNR", "SNR", "BER")])
+
+
 def _lp_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")
         model, flat, res = _lp_epoch(dev, _lp_dataset())
+        ev = _lp_eval(model, dev)
         if rank == 0:
+            ret["eval"] = ev
             ret["param"] = flat.flat_param.cpu()
             ret["rm"], ret["rv"] = model.norm1.module.running_mean.cpu(), model.norm1.module.running_var.cpu()
             ret["nbt"] = int(model.norm1.module.num_batches_tracked)
@@ -156,6 +176,12 @@ def test_two_rank_lightpath_epoch_with_lut_less_shards_matches_single_process():
     assert rel_err(got["rm"], model.norm1.module.running_mean.cpu()) < 2e-5
     assert rel_err(got["rv"], model.norm1.module.running_var.cpu()) < 2e-5
     assert rel_err(got["param"], flat.flat_param.cpu()) < 5e-5
+    # evaluate(): the LUT skip is a property of the GLOBAL batch under data parallelism too
+    ev = _lp_eval(model, dev)
+    assert got["eval"]["skipped"] == ev["skipped"] == 8
+    assert got["eval"]["rows"] == ev["rows"] == 14
+    assert rel_err(got["eval"]["y_pred"], ev["y_pred"]) < 5e-5
+    assert all(abs(a - b) <= 1e-4 * max(1.0, abs(b)) for a, b in zip(got["eval"]["r2"], ev["r2"]))
 
 
 # --------------------------------------------------------------------------- RCCL itself, as far as one GPU allows
@@ -172,11 +198,23 @@ def _rccl_world1_worker(rank, world, port, ret):
         flat.zero_grad()
         F.smooth_l1_loss(model(full.to(dev)), full.y.view(-1, 3).to(dev)).backward()
         before = flat.flat_grad.clone()
-        flat.all_reduce_grads()
-        scale = dp.loss_scale(5, dev)
-        torch.cuda.synchronize()
+        assert float(before.abs().max()) > 0
         ret["mode"] = dp.reduce_mode(flat.flat_grad)
+        flat.all_reduce_grads(force=True)          # world == 1 returns early without `force`: issue the collective
+        torch.cuda.synchronize()
         ret["same"] = bool(torch.equal(before, flat.flat_grad))
+        # the same op straight through torch.distributed, on the whole flat gradient (68 K floats at cfg2's width)
+        direct = before.clone()
+        work = dist.all_reduce(direct, op=dist.ReduceOp.AVG, async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        ret["direct_same"] = bool(torch.equal(before, direct))
+        ret["numel"] = int(direct.numel())
+        # the weighted form (LightpathGNN shards with different n_lut): sum of (w*g, w), then divide
+        flat.all_reduce_grads(weight=torch.tensor(5.0, device=dev), force=True)
+        torch.cuda.synchronize()
+        ret["weighted_close"] = float((flat.flat_grad - before).abs().max()) <= 1e-6 * float(before.abs().max())
+        scale = dp.loss_scale(5, dev)
         ret["scale"] = float(scale)
         ret["backend"] = dist.get_backend()
     finally:
@@ -185,12 +223,41 @@ def _rccl_world1_worker(rank, world, port, ret):
 
 def test_rccl_single_rank_group_runs_the_avg_all_reduce():
     """The nccl (= RCCL) backend at world size 1 on the one GPU this box has: the library loads, a communicator is
-    created, ``ReduceOp.AVG`` is accepted (``dp.reduce_mode`` == "avg"), the flat-gradient all-reduce and the loss-scale
-    exchange run on the device and leave a single rank's values unchanged.  What stays unexercised until a multi-GPU node
+    created, ``dp.reduce_mode`` == "avg", and the flat-gradient ``all_reduce(AVG)`` IS ISSUED (``force=True``: without it
+    ``all_reduce_grads`` returns early at world size 1) through ``FlatModel`` and directly, bit-equal to its input on a
+    single rank; the weighted (sum, divide) form likewise.  What stays unexercised until a multi-GPU node
     runs it is the exchange between ranks."""
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_rccl_world1_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
         got = dict(ret)
     assert got["backend"] == "nccl" and got["mode"] == "avg"
-    assert got["same"] and abs(got["scale"] - 1.0) < 1e-6
+    assert got["same"] and got["direct_same"] and got["weighted_close"] and got["numel"] > 1000
+    assert abs(got["scale"] - 1.0) < 1e-6
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo_reports_the_collective():
+    """``python bench.py --gpus 2`` (self-spawned ranks, SURVEY 8(e) / the driver's launch contract) rehearsed on the
+    one-GPU box: ``BENCH_BACKEND=gloo BENCH_SHARE_GPU=1`` puts both ranks on cuda:0.  The children are fresh processes
+    of a parent (bench.py) that never touches the GPU.  Checks the JSON line: two ranks took part in a real exchange
+    (``collective_world_size``), the flat-gradient all-reduce was timed, the loss is finite, weak scaling doubles the
+    graphs per step.  No scaling number is expected from this."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["collective_world_size"] == 2 and cfg["collective_backend"] == "gloo"
+    assert cfg["global_batch"] == 2 * cfg["graphs_per_gpu"] and line["scaling"] == "weak"
+    assert cfg["all_reduce_us"] is not None and cfg["all_reduce_us"] > 0 and cfg["all_reduce_floats"] > 1000
+    assert cfg["final_loss"] == cfg["final_loss"] and abs(cfg["final_loss"]) < 1e3
+    assert line["value"] > 0 and line["steps"] == 3

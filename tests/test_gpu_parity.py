@@ -68,6 +68,36 @@ def test_topological_fwd_bwd(cuda_device, cfg, B, n, e, H):
     _grad_compare(ref, hip)
 
 
+@pytest.mark.parametrize("D,H,p", [(6, 64, 0.0), (8, 32, 0.0), (5, 128, 0.0), (6, 64, 0.5)])
+def test_topological_edge_dim_5_to_8(cuda_device, D, H, p):
+    """The reference takes ``edge_dim = len(dataset.FEATURES)`` (``topological_training/dataset.py:40``, ``train.py:51``):
+    data-dependent.  The fused NNConv tile kernels are built for edge_dim <= 4; 5..8 (the range ``include/qot_gnn.h``
+    promises) run the materialised-operand path (``qot_nnconv_agg`` + GEMMs + ``qot_nnconv_bwd_edge``) behind the same
+    ``NNConvFn`` (ADVICE r2: the range used to raise at the first forward).  Forward and every gradient vs the oracle;
+    with dropout on, a run-to-run replay (fused-head fold + the separate activation kernel draw the same masks)."""
+    from gnn_qot_estimation_amd import synthetic as S
+    batch = S.topological_batch(2, 5, n=40, e=140, edge_dim=D)
+    ref, hip = _models("topo", cuda_device, num_nodes=40, hidden_channels=H, out_channels=3, edge_dim=D, dropout_p=p)
+    dbatch = batch.to(cuda_device)
+    y = batch.y.view(-1, 3)
+    if p > 0:
+        hip.train()
+        hip._qot_seed = 99
+        a = hip(dbatch)
+        torch.nn.functional.smooth_l1_loss(a, y.to(cuda_device)).backward()
+        assert all(torch.isfinite(q_.grad).all() for q_ in hip.parameters())
+        assert float(a.abs().max()) > 0
+        hip.eval(); ref.eval()
+        assert rel_err(hip(dbatch), ref(batch)) <= TOL
+        return
+    ref.train(); hip.train()
+    out_ref, out_hip = ref(batch), hip(dbatch)
+    assert rel_err(out_hip, out_ref) <= TOL
+    torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
+    torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
+    _grad_compare(ref, hip)
+
+
 def test_topological_isolated_nodes_and_duplicates(cuda_device):
     """Zero in-degree rows (common in the real 75-node graphs, to_graph.py:133-135),
     duplicate edges and a self loop."""
@@ -526,6 +556,51 @@ def test_csr_by_graph_equals_general_build(cuda_device):
     assert int(st.item()) & 2
     for k, v in big.items():
         assert bool((v[N + 1:] == -7).all()), k
+
+
+@pytest.mark.gpu
+def test_csr_by_graph_strided_slice_views_and_status_raise(cuda_device):
+    """``build_graph_index`` with NON-contiguous ``ptr`` / ``edge_ptr`` views: both ``.contiguous()`` results are
+    temporaries, and a pointer taken from the first used to be handed to the kernel after its block had been reused
+    by the second (round-2 GPU fault).  The product keeps both alive; the result must equal the
+    general build.  Wrong slices must raise (the kernel's status word is read back) instead of handing
+    uninitialised index arrays to the gather kernels."""
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd.graph import build_graph_index, check_index_status
+    torch.manual_seed(1)
+    sizes = [9, 31, 2, 120, 64]
+    ecnt = [30, 100, 2, 700, 0]
+    ptr = torch.tensor([0] + sizes).cumsum(0)
+    eptr = torch.tensor([0] + ecnt).cumsum(0)
+    parts = [torch.randint(0, n, (2, m)) + off for n, m, off in zip(sizes, ecnt, ptr[:-1].tolist()) if m]
+    dev = cuda_device
+    ei = torch.cat(parts, 1).to(dev)
+    N = int(ptr[-1])
+    # strided views of same-sized parents: [B+1, 2][:, 0] -- .contiguous() allocates for each
+    ptr_v = torch.stack([ptr, ptr + 1000], 1).to(dev)[:, 0]
+    eptr_v = torch.stack([eptr, eptr + 1000], 1).to(dev)[:, 0]
+    assert not ptr_v.is_contiguous() and not eptr_v.is_contiguous()
+    a = build_graph_index(ei, N)
+    for _ in range(3):                      # allocator state varies between rounds
+        b = build_graph_index(ei, N, slices=(ptr_v, eptr_v, max(sizes), max(ecnt)))
+        for name in ("rowptr", "col", "eid", "row", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg"):
+            ta, tb = getattr(a, name), getattr(b, name)
+            m = ei.shape[1] if name not in ("rowptr", "rowptr_t", "invdeg") else ta.numel()
+            assert torch.equal(ta[:m], tb[:m]), name
+        assert torch.equal(b.ptr32.long().cpu(), ptr)
+    # edge slices handed in as node slices: the kernel flags it, the product raises, the flag is cleared
+    with pytest.raises(_lib.QotError, match="inconsistent batch slices"):
+        build_graph_index(ei, N, slices=(eptr_v, eptr_v, 2048, max(ecnt)))
+    check_index_status(dev)                 # cleared by the raise
+    bad = ei.clone()
+    bad[0, 0] = N - 1                       # an edge that leaves its graph
+    with pytest.raises(_lib.QotError, match="leaves its graph"):
+        build_graph_index(bad, N, slices=(ptr_v, eptr_v, max(sizes), max(ecnt)))
+    # _lib.call takes tensors (kept alive through the launch) as well as raw pointers
+    out = torch.empty(N, dtype=torch.int32, device=dev)
+    ids = torch.arange(2 * N, device=dev)[::2]
+    _lib.call("qot_i64_to_i32", ids.contiguous(), out, N)
+    assert torch.equal(out.long(), ids)
 
 
 @pytest.mark.gpu
