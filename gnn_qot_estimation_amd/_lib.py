@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 5          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 6          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -44,6 +44,7 @@ SIGNATURES = {
                              _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_bwd_dst_workspace_floats": (_sz, [_i64, _int, _int]),
     "qot_tconv_rows_per_block": (_int, [_int]),
+    "qot_tconv_bwd_dst_blocks": (_i64, [_i64, _int, _int, _i64]),
     "qot_tconv_bwd_dst": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p,
                                  _p, _f, _f, _u64, _p, _p, _p, _int, _i64, _p, _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _i64, _p, _i64, _int,
@@ -93,6 +94,7 @@ SIGNATURES = {
     "qot_rowsum_wide": (_int, [_p, _i64, _i64, _p, _p, _p]),
     "qot_head_fwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p]),
     "qot_head_bwd_workspace_floats": (_sz, [_int, _int]),
+    "qot_head_bwd_blocks": (_int, [_i64]),
     "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p,
                             _p, _f, _f, _u64, _p, _p]),
     "qot_act_bwd_colsum": (_int, [_p, _p, _p, _i64, _int, _f, _f, _u64, _p, _p, _p, _p]),
@@ -103,9 +105,44 @@ SIGNATURES = {
     "qot_table_maps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "qot_step_advance": (_int, [_p, _p, _p]),
     "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
+    "qot_run_roles": (_int, [_p, _int, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),
 }
+
+MAX_ROLES = 12           # include/qot_gnn.h: QOT_MAX_ROLES
+ROLE_CSR_BY_GRAPH, ROLE_TABLE_PROJECT_FWD, ROLE_GATHER3, ROLE_SUM_ROWS, ROLE_NNCONV_FINALIZE64, ROLE_TABLE_PROJECT_BWD = range(1, 7)
+
+
+class Role(C.Structure):
+    """``qot_role_t`` (include/qot_gnn.h): one job of a multi-role launch."""
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p", C.c_void_p * 18), ("i", C.c_int64 * 8)]
+
+
+def make_role(kind: int, ptrs, ints) -> Role:
+    """``ptrs``: tensors / raw pointers / None in the order include/qot_gnn.h lists for ``kind``; ``ints`` likewise."""
+    r = Role()
+    r.kind = kind
+    for k, t in enumerate(ptrs):
+        r.p[k] = None if t is None else (t.data_ptr() if isinstance(t, torch.Tensor) else int(t))
+    for k, v in enumerate(ints):
+        r.i[k] = int(v)
+    return r
+
+
+def run_roles(roles, stream_handle=None):
+    """One launch for all of ``roles`` (independent jobs); raises on a non-zero status."""
+    if not roles:
+        return
+    if len(roles) > MAX_ROLES:
+        for k in range(0, len(roles), MAX_ROLES):
+            run_roles(roles[k:k + MAX_ROLES], stream_handle)
+        return
+    arr = (Role * len(roles))(*roles)
+    code = (_lib or load()).qot_run_roles(C.addressof(arr), len(roles), stream() if stream_handle is None else stream_handle)
+    if code != 0:
+        check(code, "qot_run_roles")
+
 
 _lib = None
 

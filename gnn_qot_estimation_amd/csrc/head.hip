@@ -237,6 +237,9 @@ extern "C" int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0,
     return QOT_OK;
 }
 
+// workgroups qot_head_bwd launches for B graphs (= rows of its partials workspace)
+extern "C" int qot_head_bwd_blocks(int64_t B) { return B < kHeadBwdBlocks ? (int)(B > 0 ? B : 0) : kHeadBwdBlocks; }
+
 extern "C" size_t qot_head_bwd_workspace_floats(int H, int O) {
     return (size_t)kHeadBwdBlocks * (size_t)(H * H + 2 * H + O * H + O);
 }
@@ -250,7 +253,7 @@ extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const fl
     hipStream_t stream = (hipStream_t)stream_;
     if (B <= 0 || O <= 0) return QOT_ERR_BADARG;
     if (O > 8) return QOT_ERR_UNSUPPORTED;
-    if (!grad_out || !pooled || !hidden || !ptr || !w0 || !w3 || !grad_x || !grads || !workspace) return QOT_ERR_BADARG;
+    if (!grad_out || !pooled || !hidden || !ptr || !w0 || !w3 || !grad_x || !workspace) return QOT_ERR_BADARG;
     const ActParams ap = make_act(1, slope, p, seed, step_counter);
     int blocks = kHeadBwdBlocks;
     if (B < blocks) blocks = (int)B;
@@ -258,6 +261,7 @@ extern "C" int qot_head_bwd(const float* grad_out, const float* pooled, const fl
     QOT_HEAD_H(H, head_bwd_kernel<kH><<<blocks, 256, 0, stream>>>(grad_out, pooled, hidden, ptr, w0, w3, grad_x,
                                                                   workspace, B, O, ap, x_in, in_ap));
     QOT_LAUNCH_CHECK();
+    if (!grads) return QOT_OK;            // deferred: the caller sums the block partials (QOT_ROLE_SUM_ROWS)
     const int n = H * H + H + O * H + O + (x_in ? H : 0);
     head_partial_sum_kernel<<<grid_for(n, 64), 1024, 0, stream>>>(workspace, blocks, n, grads);
     QOT_LAUNCH_CHECK();

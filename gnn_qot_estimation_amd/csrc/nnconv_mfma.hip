@@ -25,6 +25,7 @@
 // the gathered end.
 #include "common.hpp"
 #include "mfma_tile.hpp"
+#include "nnconv_finalize_dev.hpp"
 
 namespace qot {
 
@@ -398,7 +399,6 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 // (weight gradient).  512 threads = 8 waves, one workgroup per CU: every wave keeps 5 of the 40
 // 32x32 accumulator tiles of gWcat^T across the persistent loop (80 VGPRs), partials go to one slab
 // per workgroup and are summed in a fixed order afterwards (bitwise reproducible).
-constexpr int kAdjBlocksPerCu = 1;
 
 // VARIANT (diagnostic build only): 0 production; 1 every gathered row read from ONE hot address (no row-load latency);
 // 2 no grad_x loop; 3 no weight-gradient loop; 4 no gather; 5 neither MFMA loop (gather + exchange only)
@@ -931,48 +931,6 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh64_kernel(
     }
 }
 
-// One launch for both second-stage sums of the NNConv backward (H = 64): blocks [0, nb1) sum the per-workgroup
-// weight-gradient slabs of nnconv_adjoint_dw64 (16 lanes per float4 stride over the slabs, fixed butterfly) and write the
-// parameters' own layouts; the remaining blocks sum the grad-h partials (one wave per output).  Separately these were
-// three dependent launches of ~5 us each behind kernels that had long finished.
-__global__ __launch_bounds__(256) void nnconv_bwd_finalize64_kernel(const float* __restrict__ slabs, int nslabs, int64_t elems,
-                                                                    float* __restrict__ dst, int K, int nb1,
-                                                                    const float* __restrict__ hpart, int hblk, int hn, int KD,
-                                                                    float* __restrict__ gw1, float* __restrict__ gb1) {
-    if ((int)blockIdx.x >= nb1) {
-        const int t = (blockIdx.x - nb1) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if (t >= hn) return;
-        const float s = wave_sum_partials(hpart, hblk, hn, t);
-        if ((threadIdx.x & 63) == 0) { if (t < KD) gw1[t] = s; else gb1[t - KD] = s; }
-        return;
-    }
-    const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t t = gt >> 4;             // float4 index
-    const int sub = (int)(gt & 15);
-    const bool live = t * 4 < elems;
-    float4 acc = f4zero();
-    if (live)
-        for (int sidx = sub; sidx < nslabs; sidx += 16) acc = add4(acc, ld4(slabs + (int64_t)sidx * elems + 4 * t));
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
-        acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-    }
-    if (!live || sub) return;
-    const int64_t e = 4 * t;
-    const int a0 = (int)(e & 63), o_ = (int)((e >> 6) & 63), kb = (int)(e >> 12);
-    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int a = a0 + c;
-        int64_t idx;
-        if (kb < K) idx = ((int64_t)a * 64 + o_) * K + kb;
-        else if (kb == K) idx = (int64_t)4096 * K + a * 64 + o_;
-        else idx = (int64_t)4096 * (K + 1) + o_ * 64 + a;
-        dst[idx] = v[c];
-    }
-}
-
 __global__ void gradh_partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, int KD,
                                          float* __restrict__ gw1, float* __restrict__ gb1) {
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per output
@@ -1175,21 +1133,12 @@ extern "C" int qot_nnconv_gradh_fused(const float* grad_out, int ld_g, const flo
 // slabs left in adj_workspace) and qot_nnconv_gradh_fused(gw1 = gb1 = NULL: partials left in gradh_workspace).
 extern "C" int qot_nnconv_bwd_finalize(const float* adj_workspace, const float* gradh_workspace, float* grad_params,
                                        float* gw1, float* gb1, int64_t N, int H, int D, qot_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (N <= 0 || H != 64 || D < 1 || D > 4) return (H != 64 || D > 4) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
-    if (!adj_workspace || !gradh_workspace || !grad_params || !gw1 || !gb1) return QOT_ERR_BADARG;
-    int agrid = grid_for(N, 32);
-    if (agrid > num_cus() * kAdjBlocksPerCu) agrid = num_cus() * kAdjBlocksPerCu;
-    int hgrid = grid_for(N, 32);
-    if (hgrid > 2 * num_cus()) hgrid = 2 * num_cus();
-    const int K = 2 * D;
-    const int64_t elems = (int64_t)(K + 2) * 64 * 64;
-    const int nb1 = grid_for(elems / 4 * 16, 256);
-    const int hn = K * (D + 1);
-    nnconv_bwd_finalize64_kernel<<<nb1 + grid_for(hn, 4), 256, 0, stream>>>(adj_workspace, agrid, elems, grad_params, K, nb1,
-                                                                             gradh_workspace, hgrid, hn, K * D, gw1, gb1);
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
+    qot_role_t r{};                      // nnconv_bwd_finalize64_body through the multi-role launch (roles.hip)
+    r.kind = QOT_ROLE_NNCONV_FINALIZE64;
+    r.p[0] = adj_workspace; r.p[1] = gradh_workspace; r.p[2] = grad_params; r.p[3] = gw1; r.p[4] = gb1;
+    r.i[0] = N; r.i[1] = D;
+    return qot_run_roles(&r, 1, stream_);
 }
 
 // grad_x + weight gradient of NNConv in one pass (H = 64, D <= 4).  w_perm: WcatT in fragment

@@ -1,0 +1,223 @@
+// Multi-role launch: several INDEPENDENT small jobs of one train step in ONE kernel launch.
+//
+// A replayed cfg2 step was 19 launches, eleven of them 4-9 us of launch + dependency latency around a few microseconds
+// of work ("that tail is now the second-largest item of the step").  Jobs that do not depend on each
+// other do not need launches of their own: a role table (passed BY VALUE in the kernel arguments -- no device-side
+// descriptor, nothing to copy, capture-safe) gives every job a contiguous range of 256-thread workgroups, and a
+// workgroup runs the body of the job that owns its index.  The bodies are the device functions the standalone entry
+// points always ran (graph_prep_dev.hpp, small_dev.hpp, reduce_dev.hpp, nnconv_finalize_dev.hpp); those entry points
+// are now one-role calls of this launch, so every test of theirs covers this code.
+//
+// Used by the host side for
+//   forward prologue   {graph index of a block-diagonal batch | embedding-table projection (+ dropout counter) |
+//                       NNConv operand packing}                        -- three launches before (topological.py)
+//   backward epilogue  stage 1 {read-out partial sums | NNConv slab + grad-h sums | lin_edge level-1 sums | table
+//                       gradient row sum}, stage 2 {table projection backward | lin_edge level-2 sum}
+//                                                                      -- seven launches before (functional.py)
+// Jobs inside one launch MUST be independent (no job may read what another job of the same launch writes).
+#include "common.hpp"
+#include "graph_prep_dev.hpp"
+#include "mfma_tile.hpp"
+#include "nnconv_finalize_dev.hpp"
+#include "reduce_dev.hpp"
+#include "small_dev.hpp"
+
+namespace qot {
+
+struct RoleTable {
+    int n;
+    int first[QOT_MAX_ROLES + 1];       // workgroup range of role r: [first[r], first[r + 1])
+    qot_role_t role[QOT_MAX_ROLES];
+};
+
+template <typename T>
+__device__ __forceinline__ T* rp(const qot_role_t& r, int k) { return reinterpret_cast<T*>(const_cast<void*>(r.p[k])); }
+
+#define QOT_ROLE_H(H, ...)                                            \
+    switch (H) {                                                      \
+        case 16:  { constexpr int kH = 16;  __VA_ARGS__; } break;     \
+        case 32:  { constexpr int kH = 32;  __VA_ARGS__; } break;     \
+        case 64:  { constexpr int kH = 64;  __VA_ARGS__; } break;     \
+        case 128: { constexpr int kH = 128; __VA_ARGS__; } break;     \
+        case 256: { constexpr int kH = 256; __VA_ARGS__; } break;     \
+        default: break;                                               \
+    }
+
+__global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) {
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    // The table is read where it lies -- in the kernel-argument segment (it is the only argument: offset 0) -- through
+    // a pointer: indexing the by-value copy with a runtime role index made the compiler move all of it to scratch
+    // (72 B/lane); through the pointer the fields a role needs arrive by scalar loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const RoleTable __attribute__((address_space(4))) * KernargTable;
+    const RoleTable& t = *(const RoleTable*)(KernargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)t_by_value;
+#else
+    const RoleTable& t = t_by_value;
+#endif
+    int r = 0;
+    while (r + 1 < t.n && (int)blockIdx.x >= t.first[r + 1]) ++r;       // uniform; <= QOT_MAX_ROLES scalar steps
+    const qot_role_t& ro = t.role[r];
+    const int vb = (int)blockIdx.x - t.first[r];
+    switch (ro.kind) {
+    case QOT_ROLE_CSR_BY_GRAPH:
+        csr_by_graph_body(rp<const int64_t>(ro, 0), ro.i[0], ro.i[1], rp<const int64_t>(ro, 1), rp<const int64_t>(ro, 2),
+                          ro.i[2], rp<int32_t>(ro, 3), rp<int32_t>(ro, 4), rp<int32_t>(ro, 5), rp<int32_t>(ro, 6),
+                          rp<int32_t>(ro, 7), rp<int32_t>(ro, 8), rp<int32_t>(ro, 9), rp<int32_t>(ro, 10),
+                          rp<float>(ro, 11), rp<int32_t>(ro, 12), (int)ro.i[3], (int)ro.i[4], rp<const int64_t>(ro, 13),
+                          rp<int32_t>(ro, 14), rp<int32_t>(ro, 15), rp<int32_t>(ro, 16), rp<int32_t>(ro, 17), (int64_t)vb,
+                          dyn_lds);
+        break;
+    case QOT_ROLE_TABLE_PROJECT_FWD: {
+        const Proj4 p{{rp<const float>(ro, 1), rp<const float>(ro, 3), rp<const float>(ro, 5), rp<const float>(ro, 7)},
+                      {rp<const float>(ro, 2), rp<const float>(ro, 4), rp<const float>(ro, 6), rp<const float>(ro, 8)}};
+        QOT_ROLE_H((int)ro.i[1], table_project_fwd_body<kH>(rp<const float>(ro, 0), p, rp<float>(ro, 9), rp<int64_t>(ro, 10),
+                                                            rp<int64_t>(ro, 11), vb, reinterpret_cast<float*>(dyn_lds)));
+        break;
+    }
+    case QOT_ROLE_GATHER3:
+        gather3_body(rp<const float>(ro, 0), (int)ro.i[0], rp<const float>(ro, 1), (int)ro.i[1], rp<const float>(ro, 2),
+                     rp<const int32_t>(ro, 3), rp<float>(ro, 4), ro.i[2], (int64_t)vb);
+        break;
+    case QOT_ROLE_SUM_ROWS:
+        sum_rows_body(rp<const float>(ro, 0), rp<float>(ro, 1), ro.i[0], ro.i[1], ro.i[2], (int)ro.i[3], vb,
+                      reinterpret_cast<float*>(dyn_lds));
+        break;
+    case QOT_ROLE_NNCONV_FINALIZE64:
+        nnconv_bwd_finalize64_body(rp<const float>(ro, 0), (int)ro.i[2], ro.i[3], rp<float>(ro, 2), (int)ro.i[4], (int)ro.i[5],
+                                   rp<const float>(ro, 1), (int)ro.i[6], (int)ro.i[7], (int)ro.i[4] * (int)ro.i[1],
+                                   rp<float>(ro, 3), rp<float>(ro, 4), vb);
+        break;
+    case QOT_ROLE_TABLE_PROJECT_BWD: {
+        const Proj4 p{{rp<const float>(ro, 2), rp<const float>(ro, 3), rp<const float>(ro, 4), rp<const float>(ro, 5)},
+                      {nullptr, nullptr, nullptr, nullptr}};
+        QOT_ROLE_H((int)ro.i[1], table_project_bwd_body<kH>(rp<const float>(ro, 0), rp<const float>(ro, 1), p, rp<float>(ro, 6),
+                                                            rp<float>(ro, 7), rp<float>(ro, 8), (int)ro.i[0], vb,
+                                                            reinterpret_cast<float*>(dyn_lds)));
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+}  // namespace qot
+
+using namespace qot;
+
+static bool width_ok(int64_t H) { return H == 16 || H == 32 || H == 64 || H == 128 || H == 256; }
+
+// Validates role `r` (as the standalone entry point of that job always did), fills the derived fields the body reads
+// (marked "derived" in include/qot_gnn.h) and returns its workgroup count and LDS need; < 0: a QOT_ERR_* code.
+static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
+    *blocks = 0;
+    *lds = 0;
+    const void* const* p = r.p;
+    int64_t* i = r.i;
+    switch (r.kind) {
+    case QOT_ROLE_CSR_BY_GRAPH: {
+        const int64_t E = i[0], N = i[1], B = i[2], mn = i[3], me = i[4];
+        if (p[13] && (!p[14] || (E > 0 && (!p[15] || !p[16])))) return QOT_ERR_BADARG;
+        if (E < 0 || N < 0 || B <= 0 || mn < 0 || me < 0 || !p[3] || !p[7] || !p[11]) return QOT_ERR_BADARG;
+        if (N >= (int64_t(1) << 31) - 1 || E >= (int64_t(1) << 31) - 1) return QOT_ERR_UNSUPPORTED;
+        if (mn > kByGraphMaxNodes || by_graph_lds_bytes(mn, me) > kByGraphLdsMax) return QOT_ERR_UNSUPPORTED;
+        if (!p[1] || !p[2] || (E > 0 && (!p[0] || !p[4] || !p[5] || !p[6] || !p[8] || !p[9] || !p[10]))) return QOT_ERR_BADARG;
+        *blocks = B;
+        *lds = by_graph_lds_bytes(mn, me);
+        return QOT_OK;
+    }
+    case QOT_ROLE_TABLE_PROJECT_FWD: {
+        const int64_t V = i[0], H = i[1];
+        if (V <= 0 || (p[10] && !p[11])) return QOT_ERR_BADARG;
+        if (!width_ok(H)) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 10; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = V;
+        *lds = (size_t)H * 4;
+        return QOT_OK;
+    }
+    case QOT_ROLE_GATHER3: {
+        const int64_t n0 = i[0], n1 = i[1], n = i[2];
+        if (n <= 0 || n0 < 0 || n1 < 0 || n0 + n1 > 0x7fffffff) return QOT_ERR_BADARG;
+        for (int k = 0; k < 5; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = (n + 255) / 256;
+        return QOT_OK;
+    }
+    case QOT_ROLE_SUM_ROWS: {
+        const int64_t nblk = i[0], n = i[1];
+        int64_t per = i[2];
+        if (nblk <= 0 || n <= 0 || per < 0 || !p[0] || !p[1]) return QOT_ERR_BADARG;
+        if (per == 0 || per > nblk) per = nblk;
+        i[2] = per;
+        const int64_t groups = (nblk + per - 1) / per;
+        const bool v4 = (n % 4 == 0) && ((uintptr_t)p[0] % 16 == 0) && ((uintptr_t)p[1] % 16 == 0);
+        i[3] = v4 ? 1 : 0;                                   // derived: float4 columns
+        const int64_t cols = v4 ? n / 4 : n;
+        i[4] = (cols + kSumCols - 1) / kSumCols;             // derived: column blocks per group
+        *blocks = i[4] * groups;
+        *lds = (size_t)256 * 16;
+        if (*blocks > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+        return QOT_OK;
+    }
+    case QOT_ROLE_NNCONV_FINALIZE64: {
+        const int64_t N = i[0], D = i[1];
+        if (N <= 0 || D < 1) return QOT_ERR_BADARG;
+        if (D > 4) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 5; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        int64_t agrid = (N + 31) / 32;
+        if (agrid > (int64_t)num_cus() * kAdjBlocksPerCu) agrid = (int64_t)num_cus() * kAdjBlocksPerCu;
+        int64_t hgrid = (N + 31) / 32;
+        if (hgrid > 2 * (int64_t)num_cus()) hgrid = 2 * (int64_t)num_cus();
+        const int64_t K = 2 * D;
+        const int64_t elems = (K + 2) * 64 * 64;
+        const int64_t nb1 = (elems / 4 * 16 + 255) / 256;
+        const int64_t hn = K * (D + 1);
+        i[2] = agrid; i[3] = elems; i[4] = K; i[5] = nb1; i[6] = hgrid; i[7] = hn;      // derived
+        *blocks = nb1 + (hn + 3) / 4;
+        return QOT_OK;
+    }
+    case QOT_ROLE_TABLE_PROJECT_BWD: {
+        const int64_t V = i[0], H = i[1];
+        if (V <= 0) return QOT_ERR_BADARG;
+        if (!width_ok(H)) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 9; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = 4 * H + V;
+        *lds = (size_t)(512 + 4 * H) * 4;
+        return QOT_OK;
+    }
+    default:
+        return QOT_ERR_BADARG;
+    }
+}
+
+extern "C" int qot_run_roles(const qot_role_t* roles, int n_roles, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_roles < 0 || n_roles > QOT_MAX_ROLES || (n_roles > 0 && !roles)) return QOT_ERR_BADARG;
+    if (n_roles == 0) return QOT_OK;
+    RoleTable t;
+    t.n = n_roles;
+    size_t lds = 0;
+    int64_t total = 0;
+    for (int r = 0; r < n_roles; ++r) {
+        t.role[r] = roles[r];
+        int64_t blocks;
+        size_t need;
+        const int rc = plan_role(t.role[r], &blocks, &need);
+        if (rc != QOT_OK) return rc;
+        t.first[r] = (int)total;
+        total += blocks;
+        if (total > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+        if (need > lds) lds = need;
+    }
+    for (int r = n_roles; r <= QOT_MAX_ROLES; ++r) t.first[r] = (int)total;
+    {   // dynamic LDS above 64 KB has to be allowed once (the first call is outside any graph capture)
+        static size_t allowed = 64 * 1024;
+        if (lds > allowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roles_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allowed = lds;
+        }
+    }
+    roles_kernel<<<(int)total, 256, lds, stream>>>(t);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}

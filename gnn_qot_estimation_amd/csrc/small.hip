@@ -46,96 +46,6 @@ __global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict_
     }
 }
 
-// ---- table projection ------------------------------------------------------------------------
-struct Proj4 {
-    const float* w[4];      // each [H, H] (out, in)
-    const float* b[4];      // each [H]
-};
-
-// out[v, s*H + o] = b_s[o] + sum_a table[v, a] * w_s[o, a];  one block per table row, 4H threads
-template <int H>
-__global__ __launch_bounds__(4 * H) void table_project_fwd_kernel(const float* __restrict__ table, Proj4 p,
-                                                                  float* __restrict__ out, int64_t* __restrict__ counter,
-                                                                  int64_t* __restrict__ snapshot) {
-    __shared__ float row[H];
-    const int v = blockIdx.x, c = threadIdx.x;
-    if (counter && v == 0 && c == 0) {        // as step_advance_kernel: this is the forward's first launch in table mode
-        const int64_t cc = counter[0] + 1;
-        counter[0] = cc;
-        snapshot[0] = cc;
-    }
-    if (c < H) row[c] = table[(int64_t)v * H + c];
-    __syncthreads();
-    const int s = c / H, o = c % H;
-    const float* w = p.w[s] + (int64_t)o * H;
-    float acc = p.b[s][o];
-#pragma unroll
-    for (int a = 0; a < H; a += 4) {
-        const float4 ww = ld4(w + a);
-        acc = fmaf(ww.x, row[a], acc); acc = fmaf(ww.y, row[a + 1], acc);
-        acc = fmaf(ww.z, row[a + 2], acc); acc = fmaf(ww.w, row[a + 3], acc);
-    }
-    out[(int64_t)v * 4 * H + c] = acc;
-}
-
-// blocks [0, 4H): weight + bias gradient of packed row c (= s*H + o):  gw[c, a] = sum_v gp[v, c] table[v, a]
-// blocks [4H, 4H + V): table gradient row v:                          gt[v, a] = sum_c gp[v, c] w_{s(c)}[o(c), a]
-// grads: gw [4H, H] | gb [4H]   (packed q|k|v|skip order).  256 threads = H columns x PH phases of the
-// reduction index (the loops are pure latency otherwise), phases meet in LDS in a fixed order.
-template <int H>
-__global__ __launch_bounds__(256) void table_project_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ table,
-                                                                Proj4 p, float* __restrict__ gtable,
-                                                                float* __restrict__ gw, float* __restrict__ gb, int V) {
-    constexpr int PH = 256 / H;
-    __shared__ float red[256];
-    __shared__ float redb[256];
-    const int a = threadIdx.x % H, ph = threadIdx.x / H;
-    float acc = 0.f, sb = 0.f;
-    if ((int)blockIdx.x < 4 * H) {
-        const int c = blockIdx.x;
-#pragma unroll 4
-        for (int v = ph; v < V; v += PH) {
-            const float g = gp[(int64_t)v * 4 * H + c];
-            acc = fmaf(g, table[(int64_t)v * H + a], acc);
-            sb += g;
-        }
-        red[threadIdx.x] = acc;
-        redb[threadIdx.x] = sb;
-        __syncthreads();
-        if (ph == 0) {
-            for (int k = 1; k < PH; ++k) { acc += red[k * H + a]; sb += redb[k * H + a]; }
-            gw[(int64_t)c * H + a] = acc;
-            if (a == 0) gb[c] = sb;
-        }
-    } else {
-        const int v = blockIdx.x - 4 * H;
-        __shared__ float g[4 * H];
-        for (int c = threadIdx.x; c < 4 * H; c += 256) g[c] = gp[(int64_t)v * 4 * H + c];
-        __syncthreads();
-#pragma unroll 4
-        for (int c = ph; c < 4 * H; c += PH) {
-            const int s = c / H, o = c % H;
-            acc = fmaf(g[c], p.w[s][(int64_t)o * H + a], acc);
-        }
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (ph == 0) {
-            for (int k = 1; k < PH; ++k) acc += red[k * H + a];
-            gtable[(int64_t)v * H + a] = acc;
-        }
-    }
-}
-
-// ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]] (0 where idx[i] < 0) ------------------------------------------
-__global__ void gather3_kernel(const float* __restrict__ s0, int n0, const float* __restrict__ s1, int n1,
-                               const float* __restrict__ s2, const int32_t* __restrict__ idx, float* __restrict__ out,
-                               int64_t n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int v = idx[i];          // v < 0: a padding slot (zero)
-    out[i] = v < 0 ? 0.f : (v < n0 ? s0[v] : (v < n0 + n1 ? s1[v - n0] : s2[v - n0 - n1]));
-}
-
 // ---- table-mode index maps in one launch: ids32 = (int) node_ids ; colf = ids[col] ; colf_t = ids[col_t]
 __global__ void table_maps_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ col,
                                   const int32_t* __restrict__ col_t, int32_t* __restrict__ ids32,
@@ -194,48 +104,38 @@ extern "C" int qot_smooth_l1(const float* pred, const float* target, int64_t n, 
     return QOT_OK;
 }
 
-#define QOT_TABLE_H(H, ...)                                           \
-    switch (H) {                                                      \
-        case 16:  { constexpr int kH = 16;  __VA_ARGS__; } break;     \
-        case 32:  { constexpr int kH = 32;  __VA_ARGS__; } break;     \
-        case 64:  { constexpr int kH = 64;  __VA_ARGS__; } break;     \
-        case 128: { constexpr int kH = 128; __VA_ARGS__; } break;     \
-        case 256: { constexpr int kH = 256; __VA_ARGS__; } break;     \
-        default: return QOT_ERR_UNSUPPORTED;                          \
-    }
-
 extern "C" int qot_table_project_fwd(const float* table, const float* wq, const float* bq, const float* wk,
                                      const float* bk, const float* wv, const float* bv, const float* ws,
                                      const float* bs, float* out, int V, int H, int64_t* step_counter,
                                      int64_t* step_snapshot, qot_stream_t stream) {
     if (V < 0 || (step_counter && !step_snapshot)) return QOT_ERR_BADARG;
     if (V == 0) return step_counter ? qot_step_advance(step_counter, step_snapshot, stream) : QOT_OK;
-    if (!table || !wq || !bq || !wk || !bk || !wv || !bv || !ws || !bs || !out) return QOT_ERR_BADARG;
-    Proj4 p{{wq, wk, wv, ws}, {bq, bk, bv, bs}};
-    QOT_TABLE_H(H, table_project_fwd_kernel<kH><<<V, 4 * kH, 0, (hipStream_t)stream>>>(table, p, out, step_counter,
-                                                                                       step_snapshot));
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
+    qot_role_t r{};
+    r.kind = QOT_ROLE_TABLE_PROJECT_FWD;
+    const void* ptrs[12] = {table, wq, bq, wk, bk, wv, bv, ws, bs, out, step_counter, step_snapshot};
+    for (int k = 0; k < 12; ++k) r.p[k] = ptrs[k];
+    r.i[0] = V; r.i[1] = H;
+    return qot_run_roles(&r, 1, stream);
 }
 
 extern "C" int qot_table_project_bwd(const float* grad_out, const float* table, const float* wq, const float* wk,
                                      const float* wv, const float* ws, float* grad_table, float* grad_w,
                                      float* grad_b, int V, int H, qot_stream_t stream) {
-    if (V <= 0) return QOT_ERR_BADARG;
-    if (!grad_out || !table || !wq || !wk || !wv || !ws || !grad_table || !grad_w || !grad_b) return QOT_ERR_BADARG;
-    Proj4 p{{wq, wk, wv, ws}, {nullptr, nullptr, nullptr, nullptr}};
-    QOT_TABLE_H(H, table_project_bwd_kernel<kH><<<4 * kH + V, 256, 0, (hipStream_t)stream>>>(
-                       grad_out, table, p, grad_table, grad_w, grad_b, V));
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
+    qot_role_t r{};
+    r.kind = QOT_ROLE_TABLE_PROJECT_BWD;
+    const void* ptrs[9] = {grad_out, table, wq, wk, wv, ws, grad_table, grad_w, grad_b};
+    for (int k = 0; k < 9; ++k) r.p[k] = ptrs[k];
+    r.i[0] = V; r.i[1] = H;
+    return qot_run_roles(&r, 1, stream);
 }
 
 extern "C" int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const float* s2,
                            const int32_t* idx, float* out, int64_t n, qot_stream_t stream) {
-    if (n < 0 || n0 < 0 || n1 < 0 || n0 + n1 > 0x7fffffff) return QOT_ERR_BADARG;
-    if (n == 0) return QOT_OK;
-    if (!s0 || !s1 || !s2 || !idx || !out) return QOT_ERR_BADARG;
-    gather3_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(s0, (int)n0, s1, (int)n1, s2, idx, out, n);
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
+    if (n == 0 && n0 >= 0 && n1 >= 0) return QOT_OK;
+    qot_role_t r{};
+    r.kind = QOT_ROLE_GATHER3;
+    const void* ptrs[5] = {s0, s1, s2, idx, out};
+    for (int k = 0; k < 5; ++k) r.p[k] = ptrs[k];
+    r.i[0] = n0; r.i[1] = n1; r.i[2] = n;
+    return qot_run_roles(&r, 1, stream);
 }

@@ -648,9 +648,11 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
         blocks = grad_part ? tile_n * grid_for(tile_B, RPB) : grid_for(N, RPB);
         tconv_bwd_dst_kernel<kH, kD><<<blocks, 256, 0, stream>>>(
             grad_out, q, k, v, ld, edge_attr, w_edge, stats, rowptr, col, eid, rowmap, grad_q, grad_skip, ld_g, escr,
-            delta, pds, pal, N, y_act, ap, grad_w_edge ? workspace : nullptr, tile_n, tile_B, grad_part);
+            delta, pds, pal, N, y_act, ap, workspace, tile_n, tile_B, grad_part);
     }));
     QOT_LAUNCH_CHECK();
+    // grad_w_edge == NULL with a workspace: the block partials [blocks, H*D] stay in the workspace and the caller sums
+    // them (QOT_ROLE_SUM_ROWS; qot_tconv_bwd_dst_blocks gives the row count)
     if (grad_w_edge) {
         const int n = H * D;
         if (blocks > 2 * kWedgeGroup) {       // two levels: groups of kWedgeGroup blocks, then the groups
@@ -666,6 +668,13 @@ extern "C" int qot_tconv_bwd_dst(const float* grad_out, const float* q, const fl
         QOT_LAUNCH_CHECK();
     }
     return QOT_OK;
+}
+
+// workgroups (= rows of lin_edge partials in the workspace) of qot_tconv_bwd_dst
+extern "C" int64_t qot_tconv_bwd_dst_blocks(int64_t N, int H, int tile_n, int64_t tile_B) {
+    if (N <= 0 || (H != 16 && H != 32 && H != 64 && H != 128 && H != 256)) return 0;
+    const int rpb = tconv_rpb(H);
+    return tile_n > 0 ? (int64_t)tile_n * ((tile_B + rpb - 1) / rpb) : (N + rpb - 1) / rpb;
 }
 
 // destinations per workgroup of the TransformerConv kernels at width H (table mode pre-reduces the table gradient over

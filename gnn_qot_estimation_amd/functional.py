@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, launch_group as LG
 from .graph import GraphIndex, require_cuda
 
 P = _lib.ptr
@@ -170,16 +170,20 @@ class TableProjectFn(torch.autograd.Function):
     parameters in place (one launch; backward one launch for all nine gradients)."""
 
     @staticmethod
-    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs, step_pair=None):
+    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs, step_pair=None, group=None):
         """``step_pair = (counter, snapshot)``: the launch also advances the dropout step counter (it is the
-        forward's first kernel in table mode; see ``qot_table_project_fwd``)."""
+        forward's first kernel in table mode; see ``qot_table_project_fwd``).  ``group`` (a ``LaunchGroup``): the job
+        joins the caller's multi-role launch instead of launching here; the output is valid after ``group.run()``."""
         require_cuda(table, wq, bq, wk, bk, wv, bv, ws, bs)
         table, wq, bq, wk, bk, wv, bv, ws, bs = (_f32c(t) for t in (table, wq, bq, wk, bk, wv, bv, ws, bs))
         V, H = table.shape
         out = torch.empty(V, 4 * H, dtype=torch.float32, device=table.device)
         cnt, snap = step_pair if step_pair is not None else (None, None)
-        _lib.call("qot_table_project_fwd", P(table), P(wq), P(bq), P(wk), P(bk), P(wv), P(bv), P(ws), P(bs), P(out),
-                  V, H, P(cnt), P(snap))
+        if group is not None and V > 0:
+            group.add(_lib.ROLE_TABLE_PROJECT_FWD, (table, wq, bq, wk, bk, wv, bv, ws, bs, out, cnt, snap), (V, H))
+        else:
+            _lib.call("qot_table_project_fwd", P(table), P(wq), P(bq), P(wk), P(bk), P(wv), P(bv), P(ws), P(bs), P(out),
+                      V, H, P(cnt), P(snap))
         ctx.save_for_backward(table, wq, wk, wv, ws)
         return out
 
@@ -189,12 +193,20 @@ class TableProjectFn(torch.autograd.Function):
         g = _f32c(g)
         V, H = table.shape
         dev = g.device
-        gt = torch.empty(V, H, dtype=torch.float32, device=dev)
-        gw = torch.empty(4 * H, H, dtype=torch.float32, device=dev)
+        gt = torch.empty(V * H, dtype=torch.float32, device=dev)
+        gw = torch.empty(4 * H * H, dtype=torch.float32, device=dev)
         gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
-        _lib.call("qot_table_project_bwd", P(g), P(table), P(wq), P(wk), P(wv), P(ws), P(gt), P(gw), P(gb), V, H)
-        return (gt, gw[:H], gb[:H], gw[H:2 * H], gb[H:2 * H], gw[2 * H:3 * H], gb[2 * H:3 * H], gw[3 * H:],
-                gb[3 * H:], None)
+        if LG.enabled():
+            # ``g`` (the table gradient) may itself be a deferred row sum of the TransformerConv backward: this job
+            # rides in stage 2 of the backward epilogue, and the epilogue is launched now -- in table mode this node
+            # is the last one of the pass
+            LG.defer(_lib.ROLE_TABLE_PROJECT_BWD, (g, table, wq, wk, wv, ws, gt, gw, gb), (V, H), stage=2)
+            LG.flush()
+        else:
+            _lib.call("qot_table_project_bwd", P(g), P(table), P(wq), P(wk), P(wv), P(ws), P(gt), P(gw), P(gb), V, H)
+        gw2 = gw.view(4 * H, H)
+        return (gt.view(V, H), gw2[:H], gb[:H], gw2[H:2 * H], gb[H:2 * H], gw2[2 * H:3 * H], gb[2 * H:3 * H], gw2[3 * H:],
+                gb[3 * H:], None, None)
 
 
 _LOSS_WS = {}
@@ -273,7 +285,7 @@ class TConvFn(torch.autograd.Function):
         delta = torch.empty(N, dtype=torch.float32, device=dev)
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
         pal = torch.empty(N, D, dtype=torch.float32, device=dev)
-        gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
+        gwe_flat = torch.empty(H * D, dtype=torch.float32, device=dev)
         rpb = _lib.load().qot_tconv_rows_per_block(H)     # destinations per workgroup
         tiled = maps is not None
         if tiled:
@@ -298,25 +310,44 @@ class TConvFn(torch.autograd.Function):
             act_args = (P(y), float(slope), float(p if act_step is not None else 0.0), int(seed), P(act_step))
         else:
             act_args = (None, 0.0, 0.0, 0, None)
+        grouped = LG.enabled()
+        # grouped: the per-workgroup lin_edge partials stay in `ws`; their sums (two levels above 256 workgroups) and the
+        # table-gradient row sum join the backward epilogue's multi-role launches instead of three launches of their own
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
                   P(edge_attr), P(w_edge), P(stats), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap),
                   gq_ptr, gs_ptr, ldg, P(escr), P(delta), P(pds), P(pal), *act_args,
-                  P(gwe), P(ws), *tile_args, N, H, D)
+                  None if grouped else P(gwe_flat), P(ws), *tile_args, N, H, D)
         _lib.call("qot_tconv_bwd_src", gs_ptr, ldg, _off(qkvs, 0), H4, P(escr), P(delta),
                   P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), P(colf_t), gk_ptr, gv_ptr,
                   ldg, *tile_args, N, H)
+        if grouped:
+            blocks = int(_lib.load().qot_tconv_bwd_dst_blocks(N, H, tile_args[0], tile_args[1]))
+            if blocks > 256:
+                per = 128
+                groups = (blocks + per - 1) // per
+                level1 = torch.empty(groups, H * D, dtype=torch.float32, device=dev)
+                LG.defer(_lib.ROLE_SUM_ROWS, (ws, level1), (blocks, H * D, per), stage=1)
+                LG.defer(_lib.ROLE_SUM_ROWS, (level1, gwe_flat), (groups, H * D, 0), stage=2)
+            else:
+                LG.defer(_lib.ROLE_SUM_ROWS, (ws, gwe_flat), (blocks, H * D, 0), stage=1)
         if not tiled:
             gq = gnode
         else:
             if gb == 1:
                 gq = gpart[0]
             else:
-                gq = torch.empty(n, H4, dtype=torch.float32, device=dev)   # table rows = sum over graph groups
-                wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
-                _lib.call("qot_rowsum_wide", P(gpart), gb, n * H4, P(gq), P(wsr))
+                gq_flat = torch.empty(n * H4, dtype=torch.float32, device=dev)   # table rows = sum over graph groups
+                if grouped:
+                    LG.defer(_lib.ROLE_SUM_ROWS, (gpart, gq_flat), (gb, n * H4, 0), stage=1)
+                else:
+                    wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
+                    _lib.call("qot_rowsum_wide", P(gpart), gb, n * H4, P(gq_flat), P(wsr))
+                gq = gq_flat.view(n, H4)
             if n < qkvs.shape[0]:                              # table rows no node refers to
+                if grouped:
+                    LG.flush()                                 # (rare: the concatenation below reads the row sum)
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
-        return gq, None, gwe, None, None, None
+        return gq, None, gwe_flat.view(H, D), None, None, None
 
 
 # ------------------------------------------------------------------ NNConv (a4)
@@ -411,6 +442,18 @@ def nnconv_pack_operands(w2, b2, wroot, k: int):
     return packed[:n_f], packed[n_f:n_f + n_a], packed[n_f + n_a:]
 
 
+def nnconv_pack(w2, b2, wroot, h: int, k: int, group=None):
+    """(Wcat, WcatT, Wk^T) in the fragment orders of the width's kernels.  ``group`` (a ``LaunchGroup``): the gather
+    joins the caller's multi-role launch; the operands are valid after ``group.run()``."""
+    allidx, n_f, n_a, n_g = nnconv_fused_indices(k, w2.device) if h == 64 else nnconv_gen_indices(h, k, w2.device)
+    packed = torch.empty(allidx.numel(), dtype=torch.float32, device=w2.device)
+    if group is not None:
+        group.add(_lib.ROLE_GATHER3, (w2, b2, wroot, allidx, packed), (w2.numel(), b2.numel(), allidx.numel()))
+    else:
+        _lib.call("qot_gather3", P(w2), w2.numel(), P(b2), b2.numel(), P(wroot), P(allidx), P(packed), allidx.numel())
+    return packed[:n_f], packed[n_f:n_f + n_a], packed[n_f + n_a:]
+
+
 GEN_WIDTHS = (16, 32, 128, 256)       # csrc/nnconv_gen.hip; 64 has its own tuned kernels (csrc/nnconv_mfma.hip)
 
 
@@ -461,9 +504,11 @@ class NNConvFn(torch.autograd.Function):
     """NNConv(aggr='mean') = aggregate-then-GEMM (see ``csrc/nnconv.hip``)."""
 
     @staticmethod
-    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex, act=None, side=None):
+    def forward(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph: GraphIndex, act=None, side=None, packed=None):
         """``side`` (dict shared with the consumer, see ``HeadFn``): the consumer's backward delivers the
-        gradient wrt the PRE-activation output and this layer's bias gradient in ``side["gbias"]``."""
+        gradient wrt the PRE-activation output and this layer's bias gradient in ``side["gbias"]``.
+        ``packed``: ``nnconv_pack(...)``'s result when the caller has already packed the operands (in the forward
+        prologue's multi-role launch)."""
         require_cuda(x, edge_attr, w1, b1, w2, b2, wroot, bias)
         x, edge_attr = _f32c(x), _f32c(edge_attr)
         w1, b1, w2, b2, wroot, bias = (_f32c(t) for t in (w1, b1, w2, b2, wroot, bias))
@@ -487,10 +532,7 @@ class NNConvFn(torch.autograd.Function):
             return NNConvFn._forward_wide_edge(ctx, x, edge_attr, w1, b1, w2, b2, wroot, bias, graph, act, side)
         # (Wcat, WcatT, Wk^T) in MFMA fragment order; every width runs gather -> LDS tile -> fp32 MFMA, the operand
         # [N, (K+2)H] never exists in HBM
-        if hin == 64:
-            wp, wp_adj, bp = nnconv_pack_operands(w2, b2, wroot, K)
-        else:
-            wp, wp_adj, bp = nnconv_pack_operands_gen(w2, b2, wroot, hin, K)
+        wp, wp_adj, bp = packed if packed is not None else nnconv_pack(w2, b2, wroot, hin, K)
         out = torch.empty(N, hout, dtype=torch.float32, device=x.device)
         _lib.call("qot_nnconv_fused", P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col),
                   P(graph.eid), P(graph.invdeg), 0, P(wp), P(bias), P(out), N, hin, D, *_act_args(act))
@@ -545,7 +587,7 @@ class NNConvFn(torch.autograd.Function):
         gb1 = torch.zeros(K, dtype=torch.float32, device=dev)
         _lib.call("qot_nnconv_bwd_edge", P(GA), K * hin, P(x), hin, P(edge_attr), P(w1), P(b1),
                   P(graph.rowptr), P(graph.col), P(graph.eid), P(graph.invdeg), P(gw1), P(gb1), N, hin, D)
-        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None, None
 
     @staticmethod
     def backward(ctx, g):
@@ -573,8 +615,10 @@ class NNConvFn(torch.autograd.Function):
         K, D = w1.shape
         dev = x.device
         hh = hin * hout
-        gw1 = torch.empty(K, D, dtype=torch.float32, device=dev)
-        gb1 = torch.empty(K, dtype=torch.float32, device=dev)
+        # (flat buffers the epilogue queue may keep alive; autograd gets views of them)
+        gw1f = torch.empty(K * D, dtype=torch.float32, device=dev)
+        gb1f = torch.empty(K, dtype=torch.float32, device=dev)
+        gw1, gb1 = gw1f.view(K, D), gb1f.view(K)
         wsh = torch.empty(_lib.load().qot_nnconv_gradh_workspace_floats(D), dtype=torch.float32, device=dev)
         gpar = torch.empty((K + 2) * hh, dtype=torch.float32, device=dev)
         gradh_args = (P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr), P(graph.col), P(graph.eid),
@@ -587,7 +631,10 @@ class NNConvFn(torch.autograd.Function):
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                       P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 2, P(ws), N, hin, D)
             _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
-            _lib.call("qot_nnconv_bwd_finalize", P(ws), P(wsh), P(gpar), P(gw1), P(gb1), N, hin, D)
+            if LG.enabled():             # both second-stage sums join the backward epilogue's multi-role launch
+                LG.defer(_lib.ROLE_NNCONV_FINALIZE64, (ws, wsh, gpar, gw1f, gb1f), (N, D), stage=1)
+            else:
+                _lib.call("qot_nnconv_bwd_finalize", P(ws), P(wsh), P(gpar), P(gw1f), P(gb1f), N, hin, D)
         else:
             # grad_x: the forward kernel over the transposed graph with the per-block transposed weights;
             # weight gradient: A^T g by slices of the result, the operand gathered 32 channels at a time
@@ -604,7 +651,7 @@ class NNConvFn(torch.autograd.Function):
             _lib.call("qot_nnconv_gradh_fused", *gradh_args, P(gw1), P(gb1), P(wsh), N, hin, D)
         # already in the parameters' own layouts (no permute / copy kernels)
         gw2, gb2, gwroot = gpar[:hh * K].view(hh, K), gpar[hh * K:hh * (K + 1)], gpar[hh * (K + 1):].view(hout, hin)
-        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None
+        return gx, None, gw1, gb1, gw2, gb2, gwroot, gbias, None, None, None, None
 
 
 # ------------------------------------------------------------------ leaky_relu + dropout (a3)
@@ -693,11 +740,15 @@ class HeadFn(torch.autograd.Function):
         dev = g.device
         gx = torch.empty(N, H, dtype=torch.float32, device=dev)
         nb = H * H + H + O * H + O
-        grads = torch.empty(nb + (H if ctx.fold else 0), dtype=torch.float32, device=dev)
+        ntot = nb + (H if ctx.fold else 0)
+        grads = torch.empty(ntot, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_head_bwd_workspace_floats(H, O), dtype=torch.float32, device=dev)
         fold_args = (P(x_in), ctx.fold[0], ctx.fold[1], ctx.fold[2], P(in_step)) if ctx.fold else (None, 0.0, 0.0, 0, None)
-        _lib.call("qot_head_bwd", P(g), P(pooled), P(hidden), P(ptr32), P(w0), P(w3), P(gx), P(grads), P(ws), B, H, O,
-                  slope, p, seed, P(step), *fold_args)
+        grouped = LG.enabled()           # the sum of the workgroup partials joins the backward epilogue's launch
+        _lib.call("qot_head_bwd", P(g), P(pooled), P(hidden), P(ptr32), P(w0), P(w3), P(gx), None if grouped else P(grads),
+                  P(ws), B, H, O, slope, p, seed, P(step), *fold_args)
+        if grouped:
+            LG.defer(_lib.ROLE_SUM_ROWS, (ws, grads), (_lib.load().qot_head_bwd_blocks(B), ntot, 0), stage=1)
         if ctx.fold:
             ctx.side["gbias"] = grads[nb:]          # the producer's bias gradient; gx is wrt its pre-activation
         gw0 = grads[:H * H].view(H, H)

@@ -86,10 +86,12 @@ def check_index_status(dev) -> None:
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False,
-                      slices=None, node_ids: Optional[torch.Tensor] = None) -> GraphIndex:
+                      slices=None, node_ids: Optional[torch.Tensor] = None, group=None) -> GraphIndex:
     """``slices = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 device tensors ``[B+1]`` and host
     ints) marks a block-diagonal batch whose graphs keep nodes and edges contiguous: the index is then
-    built by one workgroup per graph in a single launch (``qot_csr_build_by_graph``)."""
+    built by one workgroup per graph in a single launch (``qot_csr_build_by_graph``).  ``group`` (a
+    ``launch_group.LaunchGroup``): that launch is shared with the caller's other jobs -- the index is valid after
+    ``group.run()`` (the general multi-launch build ignores ``group`` and runs at once)."""
     require_cuda(edge_index)
     if edge_index.dtype != torch.long or edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must be int64 [2, E]")
@@ -127,6 +129,13 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
             # as tensors; it takes the pointers itself while its argument tuple keeps them alive.
             np_c, ep_c = node_ptr.contiguous(), edge_ptr.contiguous()
             status = _index_status(dev)
+            if group is not None and B >= 1:
+                group.add(_lib.ROLE_CSR_BY_GRAPH, (ei, np_c, ep_c, g.rowptr, g.col, g.eid, g.row, g.rowptr_t, g.col_t,
+                                                   g.pos_t, g.eid_t, g.invdeg, status, ids, g.ids32, g.colf, g.colf_t,
+                                                   g.ptr32), (E, N, B, int(max_n), int(max_m)))
+                if CHECK_INDEX_STATUS:
+                    group.post.append(lambda: check_index_status(dev))
+                return g
             _lib.call("qot_csr_build_by_graph", ei, E, N, np_c, ep_c, B, int(max_n), int(max_m), g.rowptr, g.col,
                       g.eid, g.row, g.rowptr_t, g.col_t, g.pos_t, g.eid_t, g.invdeg, status, ids, g.ids32, g.colf,
                       g.colf_t, g.ptr32)
@@ -154,8 +163,8 @@ def _cache(data) -> Optional[dict]:
     return c
 
 
-def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> GraphIndex:
-    """Cached ``GraphIndex`` of ``data.edge_index`` (rebuilt if the tensor changed)."""
+def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False, group=None) -> GraphIndex:
+    """Cached ``GraphIndex`` of ``data.edge_index`` (rebuilt if the tensor changed).  ``group``: see ``build_graph_index``."""
     ei = data.edge_index
     key = ("graph", bool(gat_self_loops))
     tag = (ei.data_ptr(), ei._version, tuple(ei.shape), int(num_nodes))
@@ -179,7 +188,7 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False) -> Graph
             and ptr.numel() == eptr.numel() and ptr.is_cuda and eptr.is_cuda):
         slices = (ptr, eptr, sizes[0], sizes[1])
     ids = getattr(data, "node_ids", None) if (slices is not None and getattr(data, "uniform_node_ids", None)) else None
-    g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids)
+    g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids, group=group)
     if c is not None:
         c[key] = (tag, g)
         if g.ptr32 is not None:       # read-out boundaries came with the index
@@ -280,7 +289,7 @@ def _detect_uniform_node_ids(data, N: int) -> None:
         pass
 
 
-def table_maps_for(data, graph: GraphIndex):
+def table_maps_for(data, graph: GraphIndex, group=None):
     """(rowmap, colf, colf_t, (B, n)) for TransformerConv's table mode, or None.
 
     Table mode needs ``node_ids == arange(n)`` repeated for every graph (what the reference's
@@ -308,6 +317,8 @@ def table_maps_for(data, graph: GraphIndex):
             c["tmaps"] = (tag, res)
         return res
     require_cuda(ids)
+    if group is not None and group.roles:
+        group.run()                   # the map kernel below reads graph.col: the index build must not wait in the group
     if ids.dtype != torch.int64:
         ids = ids.long()
     ids = ids.contiguous()

@@ -61,14 +61,19 @@ class TransformerConv(nn.Module):
         qkvs = QF.LinearFn.apply(x, w, b)             # one MFMA GEMM for q|k|v|skip
         return QF.TConvFn.apply(qkvs, edge_attr, self.lin_edge.weight, graph, None, act)
 
-    def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None, step_pair=None):
+    def forward_table(self, table, edge_attr, graph: GraphIndex, maps, act=None, step_pair=None, t4=None):
         """``conv(table[node_ids], ...)`` without materialising per-node inputs: project the
         ``[V, H]`` embedding table once (tiny GEMM, plain autograd) and gather projected rows.
         ``step_pair``: see ``QF.TableProjectFn``."""
-        t4 = QF.TableProjectFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
-                                     self.lin_key.bias, self.lin_value.weight, self.lin_value.bias,
-                                     self.lin_skip.weight, self.lin_skip.bias, step_pair)      # [V, 4H]
+        if t4 is None:
+            t4 = self.project_table(table, step_pair)
         return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps, act)
+
+    def project_table(self, table, step_pair=None, group=None):
+        """``[q|k|v|skip]`` rows of the embedding table, ``[V, 4H]``; with ``group`` the launch is shared."""
+        return QF.TableProjectFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                       self.lin_key.bias, self.lin_value.weight, self.lin_value.bias,
+                                       self.lin_skip.weight, self.lin_skip.bias, step_pair, group)
 
 
 class NNConv(nn.Module):
@@ -101,11 +106,21 @@ class NNConv(nn.Module):
                                       "topological_training/models.py:20-24")
         return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
 
-    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None, side=None):
+    def prepack(self, group=None):
+        """The (Wcat, WcatT, Wk^T) operands of the fused kernels from the current parameters (edge_dim <= 4), or ``None``
+        where the operator does not use them; with ``group`` the gather joins the caller's multi-role launch."""
+        w1, b1, w2, b2 = self._edge_mlp()
+        K, D = w1.shape
+        h = self.in_channels
+        if D > 4 or K != 2 * D or h != self.out_channels or (h != 64 and h not in QF.GEN_WIDTHS) or not w2.is_cuda:
+            return None
+        return QF.nnconv_pack(QF._f32c(w2.detach()), QF._f32c(b2.detach()), QF._f32c(self.lin.weight.detach()), h, K, group)
+
+    def forward(self, x, edge_index, edge_attr=None, graph: Optional[GraphIndex] = None, act=None, side=None, packed=None):
         if graph is None:
             graph = build_graph_index(edge_index, x.shape[0])
         w1, b1, w2, b2 = self._edge_mlp()
-        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph, act, side)
+        return QF.NNConvFn.apply(x, edge_attr, w1, b1, w2, b2, self.lin.weight, self.bias, graph, act, side, packed)
 
 
 class GATConv(nn.Module):

@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import _lib, functional as QF
+from . import _lib, functional as QF, launch_group as LG
 from .graph import batch_index_for, batch_ptr_for, cached_i32, graph_index_for, table_maps_for
 from .nn import NNConv, TransformerConv
 
@@ -117,17 +117,24 @@ class TopologicalGNN(nn.Module):
         if self._qot_hp is not None:
             return self._forward_padded(data)
         x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+        LG.drop_stale()
+        # Forward prologue: the graph index of the batch, the projected embedding table and the packed NNConv operands
+        # depend on the batch and on the parameters only, not on each other -- they share ONE multi-role launch
+        # (three launches before; launch_group.py / csrc/roles.hip)
+        grp = LG.LaunchGroup() if LG.enabled() else None
         maps = None
         if x is None or x.numel() == 0:
             n = data.node_ids.shape[0]
-            graph = graph_index_for(data, n)
-            maps = table_maps_for(data, graph)
+            graph = graph_index_for(data, n, group=grp)
+            maps = table_maps_for(data, graph, group=grp)
             self._check_node_ids(data, maps)
             if maps is None:
+                if grp is not None:
+                    grp.run()
                 x = QF.EmbedFn.apply(self.node_embeddings.weight, cached_i32(data, "node_ids"))
         else:
             n = x.shape[0]
-            graph = graph_index_for(data, n)
+            graph = graph_index_for(data, n, group=grp)
         step, step_pair = None, None
         if self.training and self.dropout.p > 0.0:
             step = torch.empty_like(self._qot_step)      # this forward's draw; backward re-reads it
@@ -135,9 +142,13 @@ class TopologicalGNN(nn.Module):
                 step_pair = (self._qot_step, step)
             else:
                 _lib.call("qot_step_advance", _lib.ptr(self._qot_step), _lib.ptr(step))
+        t4 = self.conv1.project_table(self.node_embeddings.weight, step_pair, grp) if maps is not None else None
+        packed = {layer: getattr(self, f"conv{layer}").prepack(grp) for layer in range(2, self.num_layers + 1)}
+        if grp is not None:
+            grp.run()
         if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
             x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step),
-                                         step_pair=step_pair)
+                                         step_pair=step_pair, t4=t4)
         else:
             x = self.conv1(x, edge_index, edge_attr, graph=graph, act=self._act(0, step))
         l0, l3 = self.mlp[0], self.mlp[3]
@@ -153,7 +164,7 @@ class TopologicalGNN(nn.Module):
             if last:
                 last_act = act_l
             x = getattr(self, f"conv{layer}")(x, edge_index, edge_attr, graph=graph, act=act_l,
-                                              side=side if last else None)
+                                              side=side if last else None, packed=packed[layer])
         if fused_head:
             # pool + head MLP (models.py:61-63) fused: one kernel forward, one backward
             p = self.mlp[2].p if self.training else 0.0

@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 5
+#define QOT_ABI_VERSION 6
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -140,10 +140,13 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
  * table gradient over them: grad_part[ceil(tile_B/RPB), tile_n, 4H] receives the partial sums of
  * grad_q (columns 0..H) and grad_skip (3H..4H) here and of grad_k / grad_v (H..3H) in qot_tconv_bwd_src;
  * the caller sums its first axis.  grad_q may then be NULL; grad_skip[N,H] is still written per node
- * (the source pass gathers it). */
-/* destinations per workgroup of the TransformerConv kernels at width H (1024/H today; callers size grad_part and the
- * workspace from this query, not from the formula); 0 for an unsupported width */
+ * (the source pass gathers it).
+ * destinations per workgroup of the TransformerConv kernels at width H (1024/H today; callers size grad_part and the
+ * workspace from this query, not from the formula); 0 for an unsupported width.
+ * grad_w_edge == NULL with workspace != NULL: the per-workgroup partials [qot_tconv_bwd_dst_blocks(...), H*D] are
+ * left in the workspace for the caller to sum (QOT_ROLE_SUM_ROWS of the step's backward epilogue). */
 int qot_tconv_rows_per_block(int H);
+int64_t qot_tconv_bwd_dst_blocks(int64_t N, int H, int tile_n, int64_t tile_B);
 size_t qot_tconv_bwd_dst_workspace_floats(int64_t N, int H, int D);
 int qot_tconv_bwd_dst(const float* grad_out, const float* q, const float* k, const float* v, int ld,
                       const float* edge_attr, const float* w_edge, const float* stats,
@@ -372,11 +375,14 @@ int qot_act_bwd_colsum(const float* grad_y, const float* y, float* grad_x, int64
  * x_in != NULL (the head's input, i.e. the last conv's output y = dropout(leaky_relu(conv)) with the
  * in_* activation parameters of that conv's epilogue, models.py:58-59): grad_x is then the gradient
  * wrt the CONV output (the activation backward is applied while the pool gradient is written) and
- * grads gets H more floats: its column sums = that conv's bias gradient. */
+ * grads gets H more floats: its column sums = that conv's bias gradient.
+ * grads == NULL: the per-workgroup partials [qot_head_bwd_blocks(B), H*H + H + O*H + O (+ H with x_in)] are left in
+ * the workspace for the caller to sum (QOT_ROLE_SUM_ROWS of the step's backward epilogue). */
 int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
                  const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
                  float slope, float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream);
 size_t qot_head_bwd_workspace_floats(int H, int O);
+int qot_head_bwd_blocks(int64_t B);
 int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
                  const float* w0, const float* w3, float* grad_x, float* grads, float* workspace, int64_t B,
                  int H, int O, float slope, float p, uint64_t seed, const int64_t* step_counter,
@@ -416,6 +422,49 @@ int qot_step_advance(int64_t* counter, int64_t* snapshot, qot_stream_t stream);
  * operands from nn.2.weight / nn.2.bias / lin.weight (topological_training/models.py:20-25). */
 int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const float* s2, const int32_t* idx,
                 float* out, int64_t n, qot_stream_t stream);
+
+/* ---- multi-role launch: several INDEPENDENT small jobs of one train step in ONE kernel launch -------------------
+ * The reference's step (topological_training/train.py:109-116) reaches ~60 small torch / PyG kernels around the two
+ * convolutions; on this engine the convolutions are a handful of launches and what is left are 4-9 us jobs whose
+ * cost is the launch itself.  Jobs that do not depend on each other share a launch: role r gets a contiguous
+ * range of 256-thread workgroups and runs the body of the standalone entry point of its kind (those entry points
+ * are one-role calls of this function).  The table is copied into the kernel arguments: nothing is read from the
+ * caller's array after the call returns, nothing is allocated, no synchronisation.
+ * Jobs of one call MUST be independent: none may read what another one writes.
+ *
+ * kind                        p[] (device pointers)                                       i[] (host integers)
+ * QOT_ROLE_CSR_BY_GRAPH       0 edge_index, 1 node_ptr, 2 edge_ptr, 3 rowptr, 4 col, 5 eid, 6 row, 7 rowptr_t,
+ *                             8 col_t, 9 pos_t, 10 eid_t, 11 invdeg, 12 status, 13 node_ids, 14 ids32, 15 colf,
+ *                             16 colf_t, 17 ptr32                                          0 E, 1 N, 2 B (> 0),
+ *                             (as qot_csr_build_by_graph)                                  3 max_nodes, 4 max_edges
+ * QOT_ROLE_TABLE_PROJECT_FWD  0 table, 1 wq, 2 bq, 3 wk, 4 bk, 5 wv, 6 bv, 7 ws, 8 bs, 9 out,
+ *                             10 step_counter, 11 step_snapshot (as qot_table_project_fwd)  0 V (> 0), 1 H
+ * QOT_ROLE_GATHER3            0 s0, 1 s1, 2 s2, 3 idx, 4 out (as qot_gather3)               0 n0, 1 n1, 2 n
+ * QOT_ROLE_SUM_ROWS           0 partials [nblk, n], 1 out [groups, n]:                     0 nblk, 1 n, 2 rows per
+ *                             out[g, t] = sum of partials[b, t] over the rows b of group g,   group (0 = all rows:
+ *                             fixed order (bitwise reproducible)                            one output row);
+ *                                                                                           3, 4 derived
+ * QOT_ROLE_NNCONV_FINALIZE64  0 adj_workspace, 1 gradh_workspace, 2 grad_params, 3 gw1,    0 N, 1 D; 2..7 derived
+ *                             4 gb1 (as qot_nnconv_bwd_finalize, H = 64)
+ * QOT_ROLE_TABLE_PROJECT_BWD  0 grad_out, 1 table, 2 wq, 3 wk, 4 wv, 5 ws, 6 grad_table,   0 V, 1 H
+ *                             7 grad_w, 8 grad_b (as qot_table_project_bwd)
+ * "derived" fields are filled by the library in its own copy; callers leave them 0. */
+#define QOT_MAX_ROLES 12
+enum {
+    QOT_ROLE_CSR_BY_GRAPH = 1,
+    QOT_ROLE_TABLE_PROJECT_FWD = 2,
+    QOT_ROLE_GATHER3 = 3,
+    QOT_ROLE_SUM_ROWS = 4,
+    QOT_ROLE_NNCONV_FINALIZE64 = 5,
+    QOT_ROLE_TABLE_PROJECT_BWD = 6
+};
+typedef struct qot_role {
+    int32_t kind;
+    int32_t reserved;
+    const void* p[18];
+    int64_t i[8];
+} qot_role_t;
+int qot_run_roles(const qot_role_t* roles, int n_roles, qot_stream_t stream);
 
 /* ---- row gather / scatter (LUT read-out and its adjoint) ---------------------------- */
 int qot_rows_gather(const float* x, const int32_t* idx, float* out, int64_t n_idx, int C,

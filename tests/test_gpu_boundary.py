@@ -89,6 +89,10 @@ def test_reference_lightpath_step_on_a_cpu_constructed_model_keeps_running_stati
     assert int(sd_h["norm1.module.num_batches_tracked"]) == int(sd_r["norm1.module.num_batches_tracked"]) == 2
     for k in sd_r:
         if sd_r[k].dtype.is_floating_point:
-            assert not sd_h[k].is_cuda and rel_err(sd_h[k], sd_r[k]) <= 10 * TOL, k
+            assert not sd_h[k].is_cuda, k
+            if k == "conv1.bias":      # a bias in front of a train-mode BatchNorm: gradient analytically zero, zero-initialised
+                assert float((sd_h[k] - sd_r[k]).abs().max()) <= 1e-5, k
+            else:
+                assert rel_err(sd_h[k], sd_r[k]) <= 10 * TOL, (k, rel_err(sd_h[k], sd_r[k]))
     with pytest.raises(ValueError, match="No LUT node found in the batch."):
         hip(S.lightpath_batch(4, lut=False))

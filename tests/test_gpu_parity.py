@@ -967,3 +967,82 @@ def test_topological_irregular_graphs_all_widths_and_edge_dims(cuda_device, H, D
     torch.nn.functional.smooth_l1_loss(out_ref, y).backward()
     torch.nn.functional.smooth_l1_loss(out_hip, y.to(cuda_device)).backward()
     _grad_compare(ref, hip)
+
+
+def test_multi_role_launch_equals_the_separate_launches(cuda_device):
+    """``qot_run_roles`` (csrc/roles.hip): independent jobs sharing one launch must produce exactly what their standalone
+    entry points (one-role calls of the same kernel) produce -- the forward prologue's three jobs, and row sums with
+    and without groups, float4 and scalar columns, ragged last group."""
+    from gnn_qot_estimation_amd import _lib, functional as QF, launch_group as LG, synthetic as S
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    dev = cuda_device
+    torch.manual_seed(3)
+    batch = S.topological_batch(2, 6, n=30, e=90).to(dev)
+    N, H, V, K = batch.num_nodes, 64, 30, 8
+    slices = (batch.ptr, batch.edge_ptr) + tuple(batch.graph_sizes)
+    a = build_graph_index(batch.edge_index, N, slices=slices, node_ids=batch.node_ids)
+    table = torch.randn(V, H, device=dev)
+    ws_ = [torch.randn(H, H, device=dev) for _ in range(4)]
+    bs_ = [torch.randn(H, device=dev) for _ in range(4)]
+    t4_ref = QF.TableProjectFn.apply(table, ws_[0], bs_[0], ws_[1], bs_[1], ws_[2], bs_[2], ws_[3], bs_[3])
+    w2, b2, wroot = torch.randn(H * H, K, device=dev), torch.randn(H * H, device=dev), torch.randn(H, H, device=dev)
+    pk_ref = QF.nnconv_pack(w2, b2, wroot, H, K)
+    grp = LG.LaunchGroup()
+    b = build_graph_index(batch.edge_index, N, slices=slices, node_ids=batch.node_ids, group=grp)
+    cnt, snap = torch.zeros((), dtype=torch.long, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    t4 = QF.TableProjectFn.apply(table, ws_[0], bs_[0], ws_[1], bs_[1], ws_[2], bs_[2], ws_[3], bs_[3], (cnt, snap), grp)
+    pk = QF.nnconv_pack(w2, b2, wroot, H, K, grp)
+    assert len(grp.roles) == 3
+    grp.run()
+    for name in ("rowptr", "col", "eid", "row", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg", "ids32", "colf", "colf_t", "ptr32"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(t4, t4_ref) and int(cnt) == 1 and int(snap) == 1
+    assert all(torch.equal(x, y) for x, y in zip(pk, pk_ref))
+    # row sums: [nblk, n] -> [groups, n]
+    for nblk, n, per in ((512, 4419, 0), (300, 256, 128), (64, 25600, 0), (7, 10, 3), (1, 5, 0)):
+        part = torch.randn(nblk, n, device=dev)
+        per_eff = nblk if per == 0 else per
+        groups = (nblk + per_eff - 1) // per_eff
+        out = torch.full((groups, n), float("nan"), device=dev)
+        out2 = torch.full((groups, n), float("nan"), device=dev)
+        _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, out), (nblk, n, per)),
+                        _lib.make_role(_lib.ROLE_SUM_ROWS, (part, out2), (nblk, n, per))])
+        ref = torch.stack([part[g * per_eff:(g + 1) * per_eff].double().sum(0) for g in range(groups)])
+        assert torch.equal(out, out2)                                        # fixed order: bitwise reproducible
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (nblk, n, per)
+    # a bad role is refused before anything is launched
+    with pytest.raises(_lib.QotError):
+        _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (None, out), (4, 4, 0))])
+    with pytest.raises(_lib.QotError):
+        _lib.run_roles([_lib.make_role(99, (), ())])
+
+
+def test_launch_groups_off_equals_on(cuda_device, monkeypatch):
+    """``QOT_NO_LAUNCH_GROUPS=1`` (one launch per job) and the grouped step give bit-identical outputs and gradients:
+    grouping moves launches, not arithmetic.  Also covers a second backward right after the first (the epilogue queue is
+    re-armed per backward pass) and a non-table batch (the end-of-backward callback flushes instead of TableProjectFn)."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    torch.manual_seed(5)
+    batch = S.topological_batch(2, 24, n=40, e=150).to(cuda_device)
+    plain = batch.to(cuda_device)
+    plain.uniform_node_ids = None
+    plain.edge_ptr = None
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QOT_NO_LAUNCH_GROUPS", mode)
+        torch.manual_seed(7)
+        m = q.TopologicalGNN(40, 64, 3, 4, dropout_p=0.5).to(cuda_device).train()
+        m._qot_seed = 4242
+        outs = []
+        for data in (batch, plain, batch):
+            batch._qot_cache = {}
+            m.zero_grad(set_to_none=True)
+            out = m(data)
+            torch.nn.functional.smooth_l1_loss(out, data.y.view(-1, 3)).backward()
+            outs.append((out.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        res[mode] = outs
+    for (oa, ga), (ob, gb_) in zip(res["1"], res["0"]):
+        assert torch.equal(oa, ob)
+        for x, y in zip(ga, gb_):
+            assert torch.equal(x, y)
