@@ -249,6 +249,9 @@ class TConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkvs, edge_attr, w_edge, graph: GraphIndex, maps, act=None):
         require_cuda(qkvs, edge_attr, w_edge)
+        ctx.receivers = (w_edge,)
+        # the table gradient may wait for the epilogue only when its consumer is TableProjectFn.backward (which flushes)
+        ctx.table_from_project = type(qkvs.grad_fn).__name__ == "TableProjectFnBackward"
         qkvs, edge_attr, w_edge = _f32c(qkvs), _f32c(edge_attr), _f32c(w_edge)
         H4 = qkvs.shape[1]
         H = H4 // 4
@@ -310,7 +313,7 @@ class TConvFn(torch.autograd.Function):
             act_args = (P(y), float(slope), float(p if act_step is not None else 0.0), int(seed), P(act_step))
         else:
             act_args = (None, 0.0, 0.0, 0, None)
-        grouped = LG.enabled()
+        grouped = LG.can_defer(*ctx.receivers)
         # grouped: the per-workgroup lin_edge partials stay in `ws`; their sums (two levels above 256 workgroups) and the
         # table-gradient row sum join the backward epilogue's multi-role launches instead of three launches of their own
         _lib.call("qot_tconv_bwd_dst", P(g), _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), H4,
@@ -337,14 +340,14 @@ class TConvFn(torch.autograd.Function):
                 gq = gpart[0]
             else:
                 gq_flat = torch.empty(n * H4, dtype=torch.float32, device=dev)   # table rows = sum over graph groups
-                if grouped:
+                if LG.enabled() and ctx.table_from_project:
                     LG.defer(_lib.ROLE_SUM_ROWS, (gpart, gq_flat), (gb, n * H4, 0), stage=1)
                 else:
                     wsr = torch.empty(_lib.load().qot_rowsum_wide_workspace_floats(n * H4), dtype=torch.float32, device=dev)
                     _lib.call("qot_rowsum_wide", P(gpart), gb, n * H4, P(gq_flat), P(wsr))
                 gq = gq_flat.view(n, H4)
             if n < qkvs.shape[0]:                              # table rows no node refers to
-                if grouped:
+                if LG.enabled():
                     LG.flush()                                 # (rare: the concatenation below reads the row sum)
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
         return gq, None, gwe_flat.view(H, D), None, None, None
@@ -510,6 +513,9 @@ class NNConvFn(torch.autograd.Function):
         ``packed``: ``nnconv_pack(...)``'s result when the caller has already packed the operands (in the forward
         prologue's multi-role launch)."""
         require_cuda(x, edge_attr, w1, b1, w2, b2, wroot, bias)
+        ctx.receivers = (w1, b1, w2, b2, wroot)   # who gets the (possibly deferred) parameter gradients
+        if side is not None and act is not None:
+            side["bias_param"] = bias             # the read-out's backward produces this parameter's gradient
         x, edge_attr = _f32c(x), _f32c(edge_attr)
         w1, b1, w2, b2, wroot, bias = (_f32c(t) for t in (w1, b1, w2, b2, wroot, bias))
         N, hin = x.shape
@@ -630,10 +636,18 @@ class NNConvFn(torch.autograd.Function):
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                       P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 2, P(ws), N, hin, D)
-            _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
-            if LG.enabled():             # both second-stage sums join the backward epilogue's multi-role launch
+            if LG.can_defer(*ctx.receivers):
+                # Only the epilogue consumes the grad-h kernel's partials: it goes to a side stream and shares the CUs
+                # with what follows on the main stream (the TransformerConv backward: latency-bound gathers, no MFMA)
+                # instead of running in front of it; both second-stage sums join the epilogue's multi-role launch.
+                if os.environ.get("QOT_NO_FORK"):
+                    _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
+                else:
+                    LG.fork(lambda: _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D),
+                            keep=(g, x, edge_attr, w1, b1, graph.rowptr, graph.col, graph.eid, graph.invdeg, bp, wsh))
                 LG.defer(_lib.ROLE_NNCONV_FINALIZE64, (ws, wsh, gpar, gw1f, gb1f), (N, D), stage=1)
             else:
+                _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
                 _lib.call("qot_nnconv_bwd_finalize", P(ws), P(wsh), P(gpar), P(gw1f), P(gb1f), N, hin, D)
         else:
             # grad_x: the forward kernel over the transposed graph with the per-block transposed weights;
@@ -714,6 +728,7 @@ class HeadFn(torch.autograd.Function):
         receive the gradient wrt its PRE-activation output: backward then folds that activation backward
         and the producer's bias gradient (``side["gbias"]``) into the pool-backward pass."""
         require_cuda(x, w0, b0, w3, b3)
+        ctx.receivers = (w0, b0, w3, b3)          # who gets the (possibly deferred) parameter gradients
         x, w0, b0, w3, b3 = (_f32c(t) for t in (x, w0, b0, w3, b3))
         N, H = x.shape
         O = w3.shape[0]
@@ -744,7 +759,8 @@ class HeadFn(torch.autograd.Function):
         grads = torch.empty(ntot, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_head_bwd_workspace_floats(H, O), dtype=torch.float32, device=dev)
         fold_args = (P(x_in), ctx.fold[0], ctx.fold[1], ctx.fold[2], P(in_step)) if ctx.fold else (None, 0.0, 0.0, 0, None)
-        grouped = LG.enabled()           # the sum of the workgroup partials joins the backward epilogue's launch
+        # the sum of the workgroup partials joins the backward epilogue's launch -- if nothing reads it before then
+        grouped = LG.can_defer(*ctx.receivers, ctx.side.get("bias_param") if ctx.fold else None)
         _lib.call("qot_head_bwd", P(g), P(pooled), P(hidden), P(ptr32), P(w0), P(w3), P(gx), None if grouped else P(grads),
                   P(ws), B, H, O, slope, p, seed, P(step), *fold_args)
         if grouped:

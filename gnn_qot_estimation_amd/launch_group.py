@@ -30,6 +30,22 @@ def enabled() -> bool:
     return os.environ.get("QOT_NO_LAUNCH_GROUPS", "0") != "1"
 
 
+def can_defer(*receivers) -> bool:
+    """A backward-epilogue job may be deferred only if nothing reads its output before the flush.  Its outputs are
+    gradients handed to autograd: for a LEAF whose ``.grad`` is ``None`` the engine just keeps the tensor (no kernel),
+    but an existing ``.grad`` is accumulated into AT ONCE (an add kernel that would read the still unfilled buffer),
+    and a non-leaf input (``F.pad`` of a parameter, a view, ...) hands the gradient to the next backward node at once.
+    ``receivers``: the forward inputs that receive the deferred gradients (``None`` entries are ignored)."""
+    if not enabled():
+        return False
+    for t in receivers:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_leaf or t.grad is not None:
+            return False
+    return not torch.is_grad_enabled()   # create_graph=True: AccumulateGrad clones what it is given
+
+
 class LaunchGroup:
     """Jobs launched together by ``run()``; ``post`` callables run after the launch (e.g. a status read-back)."""
 
@@ -54,33 +70,63 @@ class LaunchGroup:
 
 class _BackwardQueue:
     def __init__(self):
-        self.stages = ([], [])
-        self.keep = []
-        self.stream = None
-        self.armed = False
+        self.clear()
 
     def pending(self) -> bool:
-        return bool(self.stages[0] or self.stages[1])
+        return bool(self.stages[0] or self.stages[1] or self.forked)
 
     def clear(self):
         self.stages = ([], [])
         self.keep = []
-        self.stream = None
+        self.stream = None           # raw handle of the stream the backward nodes run on
+        self.stream_obj = None
+        self.forked = []             # side streams with work the epilogue has to wait for
         self.armed = False
 
 
 _Q = _BackwardQueue()
 
 
-def defer(kind: int, ptrs, ints, stage: int = 1, keep=()):
-    """Register a backward-epilogue job (``stage`` 1 or 2).  Only valid inside an autograd backward pass: the first job
-    of a pass installs the engine's end-of-backward callback that launches whatever is still pending."""
+def _arm():
     q = _Q
     if not q.armed:
         q.clear()                        # anything left over belongs to a backward pass that died: its buffers are gone
         q.stream = _lib.stream()         # node execution runs on the forward's stream; the callback may not
+        q.stream_obj = torch.cuda.current_stream()
         torch.autograd.Variable._execution_engine.queue_callback(flush)
         q.armed = True
+    return q
+
+
+_SIDE = {}
+
+
+def fork(fn, keep=()):
+    """Run ``fn()`` (kernel launches through ``_lib.call``) on a side stream, ordered behind everything enqueued so far on
+    the current stream, and let the current stream go on; the backward epilogue waits for it.  For a kernel whose result
+    only the epilogue consumes and that uses other hardware than what follows it on the main stream (NNConv's grad-h
+    kernel -- matrix cores, LDS -- next to the latency-bound TransformerConv backward kernels): the two then share the
+    CUs instead of running back to back.  ``keep``: every tensor the forked work touches -- the caching allocator must
+    not hand their blocks to main-stream allocations before the join.  Inside a backward pass only; capture-safe (the
+    side stream joins the capture at the fork and leaves it at the flush)."""
+    q = _arm()
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    side = _SIDE.get(key)
+    if side is None:
+        side = _SIDE[key] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        fn()
+    if side not in q.forked:
+        q.forked.append(side)
+    q.keep.extend(keep)
+
+
+def defer(kind: int, ptrs, ints, stage: int = 1, keep=()):
+    """Register a backward-epilogue job (``stage`` 1 or 2).  Only valid inside an autograd backward pass: the first job
+    of a pass installs the engine's end-of-backward callback that launches whatever is still pending."""
+    q = _arm()
     q.stages[stage - 1].append(_lib.make_role(kind, ptrs, ints))
     q.keep.extend(t for t in ptrs if isinstance(t, torch.Tensor))
     q.keep.extend(keep)
@@ -93,15 +139,17 @@ def flush():
         q.armed = False
         return
     s1, s2 = q.stages
-    stream = q.stream
-    q.stages = ([], [])
+    stream, forked = q.stream, q.forked
+    q.stages, q.forked = ([], []), []
     try:
+        for side in forked:              # join: the jobs below read what the forked kernels wrote
+            q.stream_obj.wait_stream(side)
         _lib.run_roles(s1, stream)
         _lib.run_roles(s2, stream)
     finally:
         q.keep = []
         q.armed = False
-        q.stream = None
+        q.stream = q.stream_obj = None
 
 
 def drop_stale():
