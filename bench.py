@@ -85,9 +85,9 @@ class TrainStep:
         if not os.environ.get("BENCH_PREP_OUTSIDE"):
             self.batch._qot_cache = {}       # graph prep (CSR/CSC build) is part of every step
         self.flat.detach_grads()             # zero_grad(set_to_none=True): autograd assigns, no add kernels
-        out = self.model(self.batch)
-        # SmoothL1Loss value + gradient from one kernel, then backward from the model output
-        _, g = QF.smooth_l1_loss_and_grad(out, self.y, loss_out=self.loss)
+        # forward with the criterion (SmoothL1Loss, mean) folded into the read-out head's kernel: out, loss value
+        # (written with the backward epilogue) and d loss / d out; then backward from the model output
+        out, _, g = self.model.forward_loss(self.batch, self.y, loss_out=self.loss)
         out.backward(g)
         if self.world > 1:
             self.flat.gather_grads()         # one kernel packs all gradients into the flat buffer RCCL reduces

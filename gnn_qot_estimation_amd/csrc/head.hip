@@ -15,8 +15,10 @@ template <int H>
 __global__ __launch_bounds__(256) void head_fwd_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ ptr, const float* __restrict__ w0,
     const float* __restrict__ b0, const float* __restrict__ w3, const float* __restrict__ b3,
-    float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ out, int O, ActParams act) {
+    float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ out, int O, ActParams act,
+    const float* __restrict__ target, float beta, float inv_n, float* __restrict__ grad_out, float* __restrict__ loss_rows) {
     __shared__ float4 red[256];
+    __shared__ float lrow[8];
     __shared__ float p[H];
     __shared__ float h[H];
     constexpr int TPR = H / 4, RPB = 256 / TPR;
@@ -52,6 +54,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
         float v = b3[o];
         for (int a = 0; a < H; ++a) v = fmaf(w3[o * H + a], h[a], v);
         out[b * O + o] = v;
+        if (target) {          // SmoothL1Loss(reduction = mean, beta) of this graph's row: gradient now, value summed later
+            const float d = v - target[b * O + o];
+            const float ad = fabsf(d);
+            float l, g;
+            if (ad < beta) { l = 0.5f * d * d / beta; g = d / beta; }
+            else           { l = ad - 0.5f * beta;    g = d > 0.f ? 1.f : -1.f; }
+            grad_out[b * O + o] = g * inv_n;
+            lrow[o] = l * inv_n;
+        }
+    }
+    if (target) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = lrow[0];
+            for (int o = 1; o < O; ++o) s += lrow[o];
+            loss_rows[b] = s;
+        }
     }
 }
 
@@ -223,18 +242,30 @@ using namespace qot;
         default: return QOT_ERR_UNSUPPORTED;                          \
     }
 
+extern "C" int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const float* b0,
+                                 const float* w3, const float* b3, float* pooled, float* hidden, float* out,
+                                 int64_t B, int H, int O, float slope, float p, uint64_t seed,
+                                 const int64_t* step_counter, const float* target, float beta, float* grad_out,
+                                 float* loss_rows, qot_stream_t stream) {
+    if (B < 0 || O <= 0 || O > 8) return (O > 8) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
+    if (B == 0) return QOT_OK;
+    if (!x || !ptr || !w0 || !b0 || !w3 || !b3 || !pooled || !hidden || !out) return QOT_ERR_BADARG;
+    if (target && (!grad_out || !loss_rows || !(beta > 0.f))) return QOT_ERR_BADARG;
+    const ActParams ap = make_act(1, slope, p, seed, step_counter);
+    const float inv_n = 1.0f / ((float)B * (float)O);
+    QOT_HEAD_H(H, head_fwd_kernel<kH><<<(int)B, 256, 0, (hipStream_t)stream>>>(x, ptr, w0, b0, w3, b3, pooled, hidden,
+                                                                              out, O, ap, target, beta, inv_n, grad_out,
+                                                                              loss_rows));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0,
                             const float* w3, const float* b3, float* pooled, float* hidden, float* out,
                             int64_t B, int H, int O, float slope, float p, uint64_t seed,
                             const int64_t* step_counter, qot_stream_t stream) {
-    if (B < 0 || O <= 0 || O > 8) return (O > 8) ? QOT_ERR_UNSUPPORTED : QOT_ERR_BADARG;
-    if (B == 0) return QOT_OK;
-    if (!x || !ptr || !w0 || !b0 || !w3 || !b3 || !pooled || !hidden || !out) return QOT_ERR_BADARG;
-    const ActParams ap = make_act(1, slope, p, seed, step_counter);
-    QOT_HEAD_H(H, head_fwd_kernel<kH><<<(int)B, 256, 0, (hipStream_t)stream>>>(x, ptr, w0, b0, w3, b3, pooled, hidden,
-                                                                              out, O, ap));
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
+    return qot_head_fwd_loss(x, ptr, w0, b0, w3, b3, pooled, hidden, out, B, H, O, slope, p, seed, step_counter, nullptr,
+                             1.0f, nullptr, nullptr, stream);
 }
 
 // workgroups qot_head_bwd launches for B graphs (= rows of its partials workspace)

@@ -634,20 +634,23 @@ class NNConvFn(torch.autograd.Function):
             # and the block sum of the grad-h kernel share one launch behind both kernels
             gx = torch.empty(N, hin, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.load().qot_nnconv_adjoint_dw_workspace_floats(D), dtype=torch.float32, device=dev)
+            deferred = LG.can_defer(*ctx.receivers)
+            # QOT_FORK (experiment, default off): the grad-h kernel on a side stream, "before" = next to the adjoint
+            # kernel, "after" = next to the TransformerConv backward that follows on the main stream
+            fork_mode = os.environ.get("QOT_FORK", "off") if deferred else "off"
+            launch_gradh = lambda: _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
+            keep = (g, x, edge_attr, w1, b1, graph.rowptr, graph.col, graph.eid, graph.invdeg, bp, wsh)
+            if fork_mode == "before":
+                LG.fork(launch_gradh, keep=keep)
             _lib.call("qot_nnconv_adjoint_dw", P(g), hout, P(x), hin, P(edge_attr), P(w1), P(b1), P(graph.rowptr_t),
                       P(graph.col_t), P(graph.eid_t), P(graph.invdeg), P(wp_adj), P(gx), P(gpar), 2, P(ws), N, hin, D)
-            if LG.can_defer(*ctx.receivers):
-                # Only the epilogue consumes the grad-h kernel's partials: it goes to a side stream and shares the CUs
-                # with what follows on the main stream (the TransformerConv backward: latency-bound gathers, no MFMA)
-                # instead of running in front of it; both second-stage sums join the epilogue's multi-role launch.
-                if os.environ.get("QOT_NO_FORK"):
-                    _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
-                else:
-                    LG.fork(lambda: _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D),
-                            keep=(g, x, edge_attr, w1, b1, graph.rowptr, graph.col, graph.eid, graph.invdeg, bp, wsh))
+            if fork_mode == "after":
+                LG.fork(launch_gradh, keep=keep)
+            elif fork_mode != "before":
+                launch_gradh()
+            if deferred:             # both second-stage sums join the backward epilogue's multi-role launch
                 LG.defer(_lib.ROLE_NNCONV_FINALIZE64, (ws, wsh, gpar, gw1f, gb1f), (N, D), stage=1)
             else:
-                _lib.call("qot_nnconv_gradh_fused", *gradh_args, None, None, P(wsh), N, hin, D)
                 _lib.call("qot_nnconv_bwd_finalize", P(ws), P(wsh), P(gpar), P(gw1f), P(gb1f), N, hin, D)
         else:
             # grad_x: the forward kernel over the transposed graph with the per-block transposed weights;
@@ -722,8 +725,12 @@ class HeadFn(torch.autograd.Function):
     backward and all four parameter gradients)."""
 
     @staticmethod
-    def forward(ctx, x, ptr32, w0, b0, w3, b3, B, act, in_act=None, side=None):
-        """``in_act`` / ``side``: the producer of ``x`` applied ``dropout(leaky_relu(.))`` in its epilogue
+    def forward(ctx, x, ptr32, w0, b0, w3, b3, B, act, in_act=None, side=None, loss=None):
+        """``loss = (target [B, O], beta, loss_out 0-dim)``: the train step's criterion (``SmoothL1Loss(mean, beta)``,
+        ``topological_training/train.py:69,113-115``) rides in the same kernel: returns ``(out, grad_out)`` with
+        ``grad_out = d loss / d out`` (feed it to ``out.backward``); ``loss_out`` receives the loss value with the
+        backward epilogue (it is the sum of per-graph shares, summed where the other partials are summed).
+        ``in_act`` / ``side``: the producer of ``x`` applied ``dropout(leaky_relu(.))`` in its epilogue
         (``in_act = (slope, p, seed, step)``) and has agreed (same ``side`` dict handed to its Function) to
         receive the gradient wrt its PRE-activation output: backward then folds that activation backward
         and the producer's bias gradient (``side["gbias"]``) into the pool-backward pass."""
@@ -737,18 +744,35 @@ class HeadFn(torch.autograd.Function):
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         hidden = torch.empty(B, H, dtype=torch.float32, device=dev)
         out = torch.empty(B, O, dtype=torch.float32, device=dev)
-        _lib.call("qot_head_fwd", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H, O,
-                  float(slope), float(p if step is not None else 0.0), int(seed), P(step))
+        gout = loss_rows = None
+        if loss is not None:
+            target, beta, loss_out = loss
+            target = _f32c(target.detach())
+            if target.shape != (B, O):
+                raise ValueError(f"target must be [{B}, {O}], got {tuple(target.shape)}")
+            gout = torch.empty(B, O, dtype=torch.float32, device=dev)
+            loss_rows = torch.empty(B, dtype=torch.float32, device=dev)
+            _lib.call("qot_head_fwd_loss", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H,
+                      O, float(slope), float(p if step is not None else 0.0), int(seed), P(step), P(target), float(beta),
+                      P(gout), P(loss_rows))
+            ctx.loss = (loss_rows, loss_out)
+        else:
+            _lib.call("qot_head_fwd", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H, O,
+                      float(slope), float(p if step is not None else 0.0), int(seed), P(step))
+            ctx.loss = None
         fold = in_act is not None and side is not None
         ctx.save_for_backward(ptr32, w0, w3, pooled, hidden, step, x if fold else None,
                               in_act[3] if fold else None)
         ctx.cfg = (N, H, O, B, float(slope), float(p if step is not None else 0.0), int(seed))
         ctx.fold = (float(in_act[0]), float(in_act[1] if in_act[3] is not None else 0.0), int(in_act[2])) if fold else None
         ctx.side = side if fold else None
+        if loss is not None:
+            ctx.mark_non_differentiable(gout)
+            return out, gout
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_gout=None):
         ptr32, w0, w3, pooled, hidden, step, x_in, in_step = ctx.saved_tensors
         N, H, O, B, slope, p, seed = ctx.cfg
         g = _f32c(g)
@@ -765,13 +789,20 @@ class HeadFn(torch.autograd.Function):
                   P(ws), B, H, O, slope, p, seed, P(step), *fold_args)
         if grouped:
             LG.defer(_lib.ROLE_SUM_ROWS, (ws, grads), (_lib.load().qot_head_bwd_blocks(B), ntot, 0), stage=1)
+        if ctx.loss is not None:         # the loss value: sum of the per-graph shares the forward left behind
+            loss_rows, loss_out = ctx.loss
+            role = (_lib.ROLE_SUM_ROWS, (loss_rows, loss_out), (B, 1, 0))
+            if LG.enabled():
+                LG.defer(*role, stage=1)
+            else:
+                _lib.run_roles([_lib.make_role(*role)])
         if ctx.fold:
             ctx.side["gbias"] = grads[nb:]          # the producer's bias gradient; gx is wrt its pre-activation
         gw0 = grads[:H * H].view(H, H)
         gb0 = grads[H * H:H * H + H]
         gw3 = grads[H * H + H:H * H + H + O * H].view(O, H)
         gb3 = grads[H * H + H + O * H:H * H + H + O * H + O]
-        return gx, None, gw0, gb0, gw3, gb3, None, None, None, None
+        return gx, None, gw0, gb0, gw3, gb3, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ GATConv (a7)

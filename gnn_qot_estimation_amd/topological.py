@@ -107,7 +107,23 @@ class TopologicalGNN(nn.Module):
         shadow.dropout.p = shadow.mlp[2].p = self.dropout.p
         return torch.func.functional_call(shadow, padded.topological_params(self, self._qot_hp), (data,))
 
+    def forward_loss(self, data, target, beta: float = 1.0, loss_out=None):
+        """``out = self(data)`` together with the train step's criterion ``SmoothL1Loss(reduction="mean", beta)(out,
+        target)`` (``topological_training/train.py:69,112-113``): returns ``(out, loss, grad_out)`` with ``grad_out =
+        d loss / d out``, so that the step reads ``out, loss, g = model.forward_loss(data, y); out.backward(g)``.  Where
+        the read-out head runs fused (hidden 16 ... 128) the criterion rides in the head's kernel and ``loss`` is written
+        with the backward epilogue (valid after ``backward``); elsewhere ``functional.smooth_l1_loss_and_grad``."""
+        res = self._forward(data, (target, float(beta), loss_out))
+        if isinstance(res, tuple):
+            out, gout, loss = res
+            return out, loss, gout
+        loss, gout = QF.smooth_l1_loss_and_grad(res, target, beta, loss_out=loss_out)
+        return res, loss, gout
+
     def forward(self, data):
+        return self._forward(data, None)
+
+    def _forward(self, data, loss_spec):
         if not self.node_embeddings.weight.is_cuda:
             # a model left on the CPU (the reference's topological_training/train.py:62): opt-in upload, or a loud error
             from . import auto_device
@@ -171,6 +187,13 @@ class TopologicalGNN(nn.Module):
             seed = (self._seed() + 0x9E3779B97F4A7C15 * 97) & 0xFFFFFFFFFFFFFFFF
             act = (self.mlp[1].negative_slope, p, seed, step if p > 0.0 else None)
             ptr, B = batch_ptr_for(data, n)
+            if loss_spec is not None and torch.is_grad_enabled():
+                target, beta, loss_out = loss_spec
+                if loss_out is None:
+                    loss_out = torch.empty((), dtype=torch.float32, device=x.device)
+                out, gout = QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
+                                            last_act if side is not None else None, side, (target, beta, loss_out))
+                return out, gout, loss_out
             return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
                                    last_act if side is not None else None, side)
         b32, ptr, B = batch_index_for(data, n)

@@ -381,6 +381,14 @@ int qot_act_bwd_colsum(const float* grad_y, const float* y, float* grad_x, int64
 int qot_head_fwd(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
                  const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
                  float slope, float p, uint64_t seed, const int64_t* step_counter, qot_stream_t stream);
+/* As qot_head_fwd, with the criterion of the train step folded in (topological_training/train.py:69,113-115:
+ * SmoothL1Loss(reduction="mean", beta) on out vs target[B,O]): also writes grad_out[B,O] = d loss / d out and
+ * loss_rows[B] = each graph's share of the mean loss; the loss value is the sum of loss_rows (the caller sums it
+ * where it sums its other partials: QOT_ROLE_SUM_ROWS).  Replaces the separate qot_smooth_l1 launch of a step. */
+int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
+                      const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
+                      float slope, float p, uint64_t seed, const int64_t* step_counter, const float* target,
+                      float beta, float* grad_out, float* loss_rows, qot_stream_t stream);
 size_t qot_head_bwd_workspace_floats(int H, int O);
 int qot_head_bwd_blocks(int64_t B);
 int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
