@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--cpu-sample-graphs", type=int, default=64)
+    ap.add_argument("--no-lightpath", action="store_true", help="skip the separate LightpathGNN (configs[2]) measurement")
+    ap.add_argument("--lightpath-steps", type=int, default=10)
     return ap.parse_args()
 
 
@@ -289,6 +291,81 @@ def cpu_baseline(sample_graphs):
                        f"host has {ncpu} cores), torch {torch.__version__} CPU")
 
 
+LP = dict(cfg=3, B=65536, F=5, C=128, heads=4, layers=3, out=3)
+
+
+def lightpath_measurement(device, steps):
+    """BASELINE.json configs[2] -- the OTHER model north_star names (lightpath_training/models.py:26-45): 65 536 per-lightpath
+    chain graphs (2..20 nodes), 3 x (GATConv heads=4 C=128 + BatchNorm + ReLU), LUT read-out, SmoothL1, SGD(momentum) --
+    as a SEPARATE object of the JSON line (never ``value``).  Eager launches (the step is ~35 ms of GPU work: launch gaps
+    do not matter), every graph distinct, graph index rebuilt in every step, median of per-step event times.
+    Algorithmic figures as SURVEY.md 8(d) prices the path, at the GENERATED sizes (N nodes, E' = E + N edges with the
+    self loops GATConv adds, B graphs, W = heads * C): per conv layer forward 8NW + 4E' + 4(N + B) bytes, backward
+    12NW + 8E' + 4(N + B); BatchNorm as its own read + write pass each way: 16NW per layer; LUT rows and head: 24BW;
+    flops: the dense projections, 2 N W (F + (L - 1) W) forward, twice that backward minus the first layer's grad_x."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import _lib, synthetic as S
+    from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+    from gnn_qot_estimation_amd import functional as QFn
+    batch = S.lightpath_batch(LP["B"], cfg=LP["cfg"]).to(device)
+    torch.manual_seed(0)
+    model = q.LightpathGNN(LP["F"], LP["C"], LP["out"], 1, dropout_p=0.5, num_layers=LP["layers"]).to(device).train()
+    flat = FlatModel(model)
+    opt = FusedSGD(flat, lr=0.01, momentum=0.9)
+    loss_t = torch.zeros((), device=device)
+
+    def step():
+        batch._qot_cache = {}
+        flat.detach_grads()
+        out, lb = model(batch)
+        _, g = QFn.smooth_l1_loss_and_grad(out, batch.y[lb], loss_out=loss_t)
+        out.backward(g)
+        opt.step(grads=True)
+
+    for _ in range(3):
+        step()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i in range(steps):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    mean = evs[0].elapsed_time(evs[steps]) / steps
+    loss = float(loss_t.item())
+    N, B, W, L, F_ = batch.num_nodes, batch.num_graphs, LP["heads"] * LP["C"], LP["layers"], LP["F"]
+    E = batch.num_edges + N
+    conv = (8 * N * W + 4 * E + 4 * (N + B)) + (12 * N * W + 8 * E + 4 * (N + B))
+    alg_bytes = L * (conv + 16 * N * W) + 24 * B * W
+    fwd_flops = 2.0 * N * W * (F_ + (L - 1) * W)
+    alg_flops = 3.0 * fwd_flops - 2.0 * N * W * F_
+    # the dominant hand-written kernel of this step, alone: the split-K weight-gradient product g^T y of the projections
+    # (csrc/gemm.hip, [W, N] x [N, W]; the forward / grad_x products run in the library)
+    g_, x_ = torch.randn(N, W, device=device), torch.randn(N, W, device=device)
+    sp = _lib.load().qot_gemm_tn_splits(W, W, N)
+    part = torch.empty(sp, W * W, device=device)
+    ms_k = event_time_ms(lambda: _lib.call("qot_gemm_tn_planes", g_, W, x_, W, part, W, W, N, sp, None, None), iters=5, warm=2,
+                         settle=True)
+    kflops = 2.0 * N * W * W
+    sec = med * 1e-3
+    return {
+        "workload": f"configs[2]: LightpathGNN {L} x (GATConv heads={LP['heads']} C={LP['C']} + BatchNorm + ReLU), LUT read-out, "
+                    f"{B} distinct chain graphs (2..20 nodes: N = {N}, E = {batch.num_edges} + {N} self loops), dropout 0.5, "
+                    "SGD momentum 0.9, SmoothL1; eager launches, graph index rebuilt in every step",
+        "graphs": B, "steps": steps, "ms_per_step": mean, "ms_per_step_median": med,
+        "graphs_per_s": B / (mean * 1e-3), "graphs_per_s_median": B / sec, "final_loss": loss, "dtype": "f32",
+        "alg_bytes_per_step": alg_bytes, "alg_flops_per_step": alg_flops,
+        "step_roofline": {"hbm_GBps": alg_bytes / sec / 1e9, "hbm_frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                          "mfma_TFLOPs": alg_flops / sec / 1e12, "mfma_frac": alg_flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS},
+        "roofline": {"bound": "mfma", "kernel": "gemm_tn_split (weight gradient g^T y of GATConv.lin)", "achieved": kflops / ms_k / 1e9,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflops / ms_k / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "alg_flops_per_launch": kflops, "alg_bytes_per_launch": 8 * N * W + 4 * W * W,
+                     "ms_per_launch": ms_k},
+    }
+
+
 def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per device) from a
     parent that never touches the GPU, relay rank 0's JSON line, fail if any rank fails."""
@@ -446,6 +523,10 @@ def main():
                                 "mfma_frac": step_flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                 "note": "per rank; algorithmic figures of SURVEY.md 8(d)"}
         res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        if world == 1 and not args.no_lightpath:
+            del step, batch, model
+            torch.cuda.empty_cache()
+            res["lightpath"] = lightpath_measurement(device, args.lightpath_steps)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)
         print(json.dumps(res))

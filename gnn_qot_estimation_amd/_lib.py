@@ -106,6 +106,9 @@ SIGNATURES = {
     "qot_table_maps": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "qot_step_advance": (_int, [_p, _p, _p]),
     "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
+    "qot_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _p, _p, _p, _p]),
+    "qot_gemm_tn_splits": (_int, [_int, _int, _i64]),
+    "qot_gemm_tn_planes": (_int, [_p, _i64, _p, _i64, _p, _int, _int, _i64, _int, _p, _p, _p]),
     "qot_run_roles": (_int, [_p, _int, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),

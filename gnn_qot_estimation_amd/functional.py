@@ -872,6 +872,54 @@ def _dist_world():
     return None, 1
 
 
+def _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, partials):
+    """``(mean, rstd, n_tot or None, world)`` of BatchNorm over the node matrix ``x`` -- batch statistics (+ in-place
+    running-statistics update) in training mode, running statistics in eval mode; see ``BnFn``."""
+    N, C = x.shape
+    dev = x.device
+    dist, world = _dist_world() if (sync and training) else (None, 1)
+    n_tot = None
+    if training and world > 1:
+        mean_l = torch.zeros(C, dtype=torch.float32, device=dev)
+        rstd_l = torch.ones(C, dtype=torch.float32, device=dev)
+        if N > 0:
+            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+            _lib.call("qot_bn_stats", P(x), N, C, float(eps), 0.0, P(mean_l), P(rstd_l), None, None, P(part))
+        m64 = mean_l.double()
+        ex2 = (1.0 / rstd_l.double().square() - eps).clamp_min(0.0) + m64 * m64 if N > 0 else m64 * 0.0
+        buf = torch.cat([m64 * N, ex2 * N, torch.tensor([float(N)], dtype=torch.float64, device=dev)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        n_tot = buf[-1].clamp_min(1.0)       # (no host read: an all-empty global batch normalises nothing)
+        mean64 = buf[:C] / n_tot
+        var64 = (buf[C:2 * C] / n_tot - mean64 * mean64).clamp_min(0.0)
+        mean = mean64.float()
+        rstd = torch.rsqrt(var64 + eps).float()
+        with torch.no_grad():
+            unbiased = var64 * (n_tot / (n_tot - 1).clamp_min(1.0))
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_(unbiased.float(), alpha=momentum)
+    elif training:
+        if N == 0:
+            raise ValueError("BatchNorm in training mode needs at least one row")
+        if N == 1:      # as torch.nn.BatchNorm1d in training mode
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {C}]")
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        if partials is not None and partials[0].numel() > 0 and C % 4 == 0:
+            part, shift = partials
+            nblk = _lib.load().qot_gat_blocks(N, 4, C // 4)
+            _lib.call("qot_bn_stats_from_partials", P(_f32c(shift)), P(part), nblk, N, C, float(eps), float(momentum),
+                      P(mean), P(rstd), P(running_mean), P(running_var))
+        else:
+            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+            _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),
+                      P(running_mean), P(running_var), P(part))
+    else:
+        mean = running_mean.detach().to(torch.float32).contiguous()
+        rstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
+    return mean, rstd, n_tot, world
+
+
 class BnFn(torch.autograd.Function):
     """BatchNorm1d over the node matrix with an optional fused ReLU.
 
@@ -893,47 +941,7 @@ class BnFn(torch.autograd.Function):
         require_cuda(x, weight, bias)
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         N, C = x.shape
-        dev = x.device
-        dist, world = _dist_world() if (sync and training) else (None, 1)
-        n_tot = None
-        if training and world > 1:
-            mean_l = torch.zeros(C, dtype=torch.float32, device=dev)
-            rstd_l = torch.ones(C, dtype=torch.float32, device=dev)
-            if N > 0:
-                part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
-                _lib.call("qot_bn_stats", P(x), N, C, float(eps), 0.0, P(mean_l), P(rstd_l), None, None, P(part))
-            m64 = mean_l.double()
-            ex2 = (1.0 / rstd_l.double().square() - eps).clamp_min(0.0) + m64 * m64 if N > 0 else m64 * 0.0
-            buf = torch.cat([m64 * N, ex2 * N, torch.tensor([float(N)], dtype=torch.float64, device=dev)])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            n_tot = buf[-1].clamp_min(1.0)       # (no host read: an all-empty global batch normalises nothing)
-            mean64 = buf[:C] / n_tot
-            var64 = (buf[C:2 * C] / n_tot - mean64 * mean64).clamp_min(0.0)
-            mean = mean64.float()
-            rstd = torch.rsqrt(var64 + eps).float()
-            with torch.no_grad():
-                unbiased = var64 * (n_tot / (n_tot - 1).clamp_min(1.0))
-                running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1.0 - momentum).add_(unbiased.float(), alpha=momentum)
-        elif training:
-            if N == 0:
-                raise ValueError("BatchNorm in training mode needs at least one row")
-            if N == 1:      # as torch.nn.BatchNorm1d in training mode
-                raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, {C}]")
-            mean = torch.empty(C, dtype=torch.float32, device=dev)
-            rstd = torch.empty(C, dtype=torch.float32, device=dev)
-            if partials is not None and partials[0].numel() > 0 and C % 4 == 0:
-                part, shift = partials
-                nblk = _lib.load().qot_gat_blocks(N, 4, C // 4)
-                _lib.call("qot_bn_stats_from_partials", P(_f32c(shift)), P(part), nblk, N, C, float(eps), float(momentum),
-                          P(mean), P(rstd), P(running_mean), P(running_var))
-            else:
-                part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
-                _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),
-                          P(running_mean), P(running_var), P(part))
-        else:
-            mean = running_mean.detach().to(torch.float32).contiguous()
-            rstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
+        mean, rstd, n_tot, world = _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, partials)
         y = torch.empty_like(x)
         if N > 0:
             _lib.call("qot_bn_apply", P(x), P(mean), P(rstd), P(weight), P(bias), P(y), N, C, int(relu))
@@ -946,29 +954,122 @@ class BnFn(torch.autograd.Function):
     def backward(ctx, g):
         x, bias, mean, rstd, weight, n_tot = ctx.saved_tensors
         training, relu, synced = ctx.cfg
-        g = _f32c(g)
-        N, C = x.shape
-        dev = x.device
-        gw = torch.zeros(C, dtype=torch.float32, device=dev)
-        gb = torch.zeros(C, dtype=torch.float32, device=dev)
-        gx = torch.empty_like(x)
-        if N > 0:
-            part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
-            _lib.call("qot_bn_bwd_reduce", P(g), None, P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
-                      P(part), P(weight), P(bias))
-        gw_use, gb_use = gw, gb
-        if synced:
-            dist, _ = _dist_world()
-            tot = torch.cat([gw, gb]).double()
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            # the kernel divides by the LOCAL row count: pre-scale the global sums by N_local / n_total
-            scale = float(N) / n_tot
-            gw_use = (tot[:C] * scale).float().contiguous()
-            gb_use = (tot[C:] * scale).float().contiguous()
-        if N > 0:
-            _lib.call("qot_bn_bwd_apply", P(g), None, P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
-                      N, C, int(relu), int(training), P(bias))
+        gx, gw, gb = _bn_backward(_f32c(g), x, bias, mean, rstd, weight, n_tot, training, relu, synced)
         return gx, gw, gb, None, None, None, None, None, None, None, None
+
+
+def _bn_backward(g, x, bias, mean, rstd, weight, n_tot, training, relu, synced):
+    """``(grad_x, grad_weight, grad_bias)`` of ``y = [relu](BatchNorm(x))`` given ``g = d/dy``; the ReLU mask is recomputed
+    from ``x``.  Shared by ``BnFn`` and ``BnLinearFn``."""
+    N, C = x.shape
+    dev = x.device
+    gw = torch.zeros(C, dtype=torch.float32, device=dev)
+    gb = torch.zeros(C, dtype=torch.float32, device=dev)
+    gx = torch.empty_like(x)
+    if N > 0:
+        part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
+        _lib.call("qot_bn_bwd_reduce", P(g), None, P(x), P(mean), P(rstd), P(gw), P(gb), N, C, int(relu),
+                  P(part), P(weight), P(bias))
+    gw_use, gb_use = gw, gb
+    if synced:
+        dist, _ = _dist_world()
+        tot = torch.cat([gw, gb]).double()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        # the kernel divides by the LOCAL row count: pre-scale the global sums by N_local / n_total
+        scale = float(N) / n_tot
+        gw_use = (tot[:C] * scale).float().contiguous()
+        gb_use = (tot[C:] * scale).float().contiguous()
+    if N > 0:
+        _lib.call("qot_bn_bwd_apply", P(g), None, P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
+                  N, C, int(relu), int(training), P(bias))
+    return gx, gw, gb
+
+
+def gemm_nt(a, b, scale=None, shift=None, bias=None):
+    """``a' @ b.T (+ bias)`` on ``qot_gemm_nt`` (``a'`` = ``relu(a * scale + shift)`` when given); ``a [M, K]``, ``b [N, K]``
+    contiguous fp32, K a multiple of 32."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.call("qot_gemm_nt", P(a), K, P(b), K, P(out), N, M, N, K, P(scale), P(shift), P(bias))
+    return out
+
+
+def gemm_tn_planes(a_t, b_t, scale=None, shift=None):
+    """``a_t.T @ b_t'`` for ``a_t [K, M]``, ``b_t [K, N]`` (``b_t'`` = ``relu(b_t * scale + shift)`` per column when given):
+    split-K planes on ``qot_gemm_tn_planes`` summed in a fixed order."""
+    K, M = a_t.shape
+    N = b_t.shape[1]
+    dev = a_t.device
+    splits = _lib.load().qot_gemm_tn_splits(M, N, K)
+    part = torch.empty(splits, M * N, dtype=torch.float32, device=dev)
+    _lib.call("qot_gemm_tn_planes", P(a_t), M, P(b_t), N, P(part), M, N, K, splits, P(scale), P(shift))
+    if splits == 1:
+        return part.view(M, N)
+    out = torch.empty(M * N, dtype=torch.float32, device=dev)
+    _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, out), (splits, M * N, 0))])
+    return out.view(M, N)
+
+
+def gemm_ok(k: int, n: int) -> bool:
+    """Shapes ``csrc/gemm.hip`` takes: inner dimension a multiple of 32, widths multiples of 4."""
+    return k % 32 == 0 and n % 4 == 0 and k >= 32
+
+
+class GemmFn(torch.autograd.Function):
+    """``x @ W^T`` (no bias) for GATConv's projection.  Forward and grad_x go to the library (measured at cfg3's shape,
+    ``tools/bench_gemm.py``: 135 TFLOP/s there against 110 for ``qot_gemm_nt``); the weight gradient ``g^T x`` -- inner
+    dimension = number of nodes, the shape the library runs at 98 TFLOP/s -- goes to ``qot_gemm_tn_planes`` (109)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        ctx.save_for_backward(x, weight)
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _f32c(g)
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        return gx, gemm_tn_planes(g, x)
+
+
+class BnLinearFn(torch.autograd.Function):
+    """``relu(BatchNorm(x)) @ W^T`` -- ``F.relu(norm(x))`` of one layer feeding ``GATConv.lin`` of the next
+    (``lightpath_training/models.py:31-32`` then ``:13,30`` of the following block) with the normalised activations NEVER
+    materialised: the projection applies ``relu(x * scale + shift)`` while it loads its operand (``qot_gemm_nt``), the
+    weight gradient recomputes it the same way (``qot_gemm_tn_planes``), the BatchNorm backward recomputes the ReLU mask
+    from ``x`` as ``BnFn`` does.  Statistics, running-statistics update and distributed behaviour are ``BnFn``'s."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, sync, partials, lin_weight):
+        require_cuda(x, weight, bias, lin_weight)
+        x, weight, bias, lin_weight = _f32c(x), _f32c(weight), _f32c(bias), _f32c(lin_weight)
+        N, C = x.shape
+        mean, rstd, n_tot, world = _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, partials)
+        scale = (rstd * weight).contiguous()                 # y = relu(x * scale + shift)
+        shift = torch.addcmul(bias, mean, scale, value=-1.0).contiguous()
+        z = gemm_nt(x, lin_weight, scale, shift) if N > 0 else x.new_empty(0, lin_weight.shape[0])
+        ctx.save_for_backward(x, bias, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0), lin_weight,
+                              scale, shift)
+        ctx.cfg = (bool(training), world > 1)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, bias, mean, rstd, weight, n_tot, lin_weight, scale, shift = ctx.saved_tensors
+        training, synced = ctx.cfg
+        gz = _f32c(gz)
+        N, C = x.shape
+        if N == 0:
+            return (torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(bias), None, None, None, None, None,
+                    None, None, torch.zeros_like(lin_weight))
+        gy = gemm_nt(gz, lin_weight.t().contiguous())        # [N, C] = gz @ W
+        g_lin = gemm_tn_planes(gz, x, scale, shift)          # [out, C] = gz^T relu(bn(x))
+        gx, gw, gb = _bn_backward(gy, x, bias, mean, rstd, weight, n_tot, training, True, synced)
+        return gx, gw, gb, None, None, None, None, None, None, None, g_lin
 
 
 # ------------------------------------------------------------------ LUT rows (a9)

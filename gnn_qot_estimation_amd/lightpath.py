@@ -9,6 +9,8 @@ and ``state_dict`` keys as ``lightpath_training/models.py:7-45`` (SURVEY.md App.
 """
 from __future__ import annotations
 
+import os
+
 from torch import nn
 
 from . import functional as QF
@@ -93,14 +95,29 @@ class LightpathGNN(nn.Module):
         x, edge_index, batch = data.x, data.edge_index, data.batch
         n = x.shape[0]
         graph = graph_index_for(data, n, gat_self_loops=True)
+        pending = None             # (norm, raw conv output, BatchNorm partials) whose BatchNorm + ReLU the next projection applies
         for layer in range(1, self.num_layers + 1):
-            conv = getattr(self, f"conv{layer}")
+            conv, norm = getattr(self, f"conv{layer}"), getattr(self, f"norm{layer}")
+            if pending is None:
+                z = conv.project(x)
+            else:                  # relu(norm(x)) @ W^T with the normalised activations never written to memory
+                pnorm, praw, ppart = pending
+                z = pnorm.project_relu(praw, conv.lin.weight, partials=ppart)
+                pending = None
             if self.training:      # the conv's epilogue leaves the BatchNorm's column partials behind
-                x, part = conv(x, edge_index, graph=graph, bn_stats=True)
-                x = getattr(self, f"norm{layer}")(x, relu=True, partials=(part, conv.bias))
+                raw, part = conv.attend(z, graph, bn_stats=True)
+                partials = (part, conv.bias)
             else:
-                x = conv(x, edge_index, graph=graph)
-                x = getattr(self, f"norm{layer}")(x, relu=True)    # BatchNorm + F.relu fused
+                raw, partials = conv.attend(z, graph), None
+            width = raw.shape[1]
+            # BatchNorm + ReLU folded into the NEXT projection's operand load (QF.BnLinearFn): opt-in.  It saves the
+            # normalised activations' round trip through HBM, but its product runs on csrc/gemm.hip's NT kernel, which
+            # the library beats by more than that at cfg3's shape.
+            if (layer < self.num_layers and QF.gemm_ok(width, width) and raw.shape[0] > 0
+                    and getattr(self, "_qot_fuse_bn_projection", os.environ.get("QOT_FUSE_BN_PROJECTION") == "1")):
+                pending = (norm, raw, partials)
+            else:
+                x = norm(raw, relu=True, partials=partials)        # BatchNorm + F.relu fused, materialised
         idx = self._lut_rows(data)
         if idx.numel() == 0:          # only with allow_empty_lut: zero rows that still hang on the graph
             return x[:0, :self.mlp[3].out_features], batch[:0]

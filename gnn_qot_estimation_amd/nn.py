@@ -157,7 +157,16 @@ class GATConv(nn.Module):
             graph = build_graph_index(edge_index, n, gat_self_loops=True)
         if not graph.gat_self_loops:
             raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
-        z = self.lin(x)
+        return self.attend(self.project(x), graph, bn_stats)
+
+    def project(self, x):
+        """``z = x W^T`` (``lin``, no bias): own MFMA kernel where the inner width allows (``csrc/gemm.hip``), the library
+        for the first layer's handful of input features."""
+        if x.is_cuda and x.dtype == torch.float32 and QF.gemm_ok(x.shape[1], self.lin.out_features) and x.shape[0] > 0:
+            return QF.GemmFn.apply(x, self.lin.weight)
+        return self.lin(x)
+
+    def attend(self, z, graph: GraphIndex, bn_stats: bool = False):
         # attention logits a[n,h] = <z[n,h,:], att[h,:]> are formed from z inside the operator (one pass over z each
         # way); their gradient returns into grad_z in the source pass of the backward
         return QF.GatFn.apply(z, self.att_src, self.att_dst, self.bias, graph, self.negative_slope, bn_stats)
@@ -184,6 +193,17 @@ class BatchNorm(nn.Module):
             partials = None
         return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
                              m.momentum, m.eps, relu, self.sync_stats, partials)
+
+    def project_relu(self, x, lin_weight, partials=None):
+        """``relu(self(x)) @ lin_weight^T`` without materialising the normalised activations (``QF.BnLinearFn``): this
+        layer's BatchNorm + ReLU ride in the operand load of the next layer's projection."""
+        m = self.module
+        if self.training:
+            m.num_batches_tracked.add_(1)
+        if partials is not None and not (self.training and QF._dist_world()[1] == 1):
+            partials = None
+        return QF.BnLinearFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum, m.eps,
+                                   self.sync_stats, partials, lin_weight)
 
 
 def global_mean_pool(x, batch, size: Optional[int] = None, data=None):

@@ -431,6 +431,20 @@ int qot_step_advance(int64_t* counter, int64_t* snapshot, qot_stream_t stream);
 int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const float* s2, const int32_t* idx,
                 float* out, int64_t n, qot_stream_t stream);
 
+/* ---- dense fp32 projections on the matrix cores (csrc/gemm.hip): GATConv's shared projection z = x W^T and its
+ * autograd (lightpath_training/models.py:13,30; train.py:128), the LUT head's first layer (models.py:17-22).
+ * qot_gemm_nt: C[M, N] = A'[M, K] . B[N, K]^T (+ bias[N]); scale != NULL: A' = relu(A * scale[k] + shift[k]) applied
+ * while the operand is loaded (BatchNorm + ReLU of the previous layer, models.py:31-32, never materialised).
+ * K multiple of 32; N, lda, ldb, ldc multiples of 4; operands 16-byte aligned.
+ * qot_gemm_tn_planes: Cpart[splits, M, N], plane z = A[Kz, M]^T . B'[Kz, N] over its chunk of K (the weight gradient
+ * g^T y, K = number of nodes; B' = relu(B * scale[n] + shift[n]) when scale != NULL); the caller sums the planes in
+ * order (QOT_ROLE_SUM_ROWS: bitwise reproducible).  M, N multiples of 4; splits = qot_gemm_tn_splits(M, N, K). */
+int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                const float* scale, const float* shift, const float* bias, qot_stream_t stream);
+int qot_gemm_tn_splits(int M, int N, int64_t K);
+int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int M, int N, int64_t K,
+                       int splits, const float* scale, const float* shift, qot_stream_t stream);
+
 /* ---- multi-role launch: several INDEPENDENT small jobs of one train step in ONE kernel launch -------------------
  * The reference's step (topological_training/train.py:109-116) reaches ~60 small torch / PyG kernels around the two
  * convolutions; on this engine the convolutions are a handful of launches and what is left are 4-9 us jobs whose

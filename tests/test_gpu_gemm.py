@@ -1,0 +1,95 @@
+"""csrc/gemm.hip: the dense fp32 projections of LightpathGNN (lightpath_training/models.py:13,30 and their autograd)
+against fp64 torch products.  Tolerance: fp32 accumulation over K terms, error <= 1e-5 of the result scale."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (128, 128, 32), (77, 512, 64), (4099, 128, 512), (1, 32, 32)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_gemm_nt_matches_fp64(cuda_device, M, N, K, affine):
+    from gnn_qot_estimation_amd import _lib
+    torch.manual_seed(0)
+    dev = cuda_device
+    A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    bias = torch.randn(N, device=dev)
+    scale, shift = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)) if affine else (None, None)
+    C = torch.full((M, N), float("nan"), device=dev)
+    _lib.call("qot_gemm_nt", A, K, B, K, C, N, M, N, K, scale, shift, bias)
+    Ad = torch.relu(A.double() * scale.double() + shift.double()) if affine else A.double()
+    ref = Ad @ B.double().t() + bias.double()
+    assert _rel(C, ref) <= 1e-5
+    # strided operands (column slices of wider matrices), no bias
+    Aw, Bw = torch.randn(M, K + 64, device=dev), torch.randn(N, K + 32, device=dev)
+    Cw = torch.full((M, N + 8), float("nan"), device=dev)
+    _lib.call("qot_gemm_nt", Aw, K + 64, Bw, K + 32, Cw, N + 8, M, N, K, None, None, None)
+    assert _rel(Cw[:, :N], Aw[:, :K].double() @ Bw[:, :K].double().t()) <= 1e-5
+    assert bool(torch.isnan(Cw[:, N:]).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (128, 512, 33), (512, 128, 100000), (4, 8, 7)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_gemm_tn_planes_sum_to_the_product(cuda_device, M, N, K, affine):
+    from gnn_qot_estimation_amd import _lib
+    torch.manual_seed(1)
+    dev = cuda_device
+    A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
+    scale, shift = (torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)) if affine else (None, None)
+    splits = _lib.load().qot_gemm_tn_splits(M, N, K)
+    assert splits >= 1
+    part = torch.full((splits, M * N), float("nan"), device=dev)
+    _lib.call("qot_gemm_tn_planes", A, M, B, N, part, M, N, K, splits, scale, shift)
+    out = torch.empty(M * N, device=dev)
+    _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, out), (splits, M * N, 0))])
+    Bd = torch.relu(B.double() * scale.double() + shift.double()) if affine else B.double()
+    ref = A.double().t() @ Bd
+    assert _rel(out.view(M, N), ref) <= 2e-5
+    part2 = torch.empty_like(part)
+    _lib.call("qot_gemm_tn_planes", A, M, B, N, part2, M, N, K, splits, scale, shift)
+    assert torch.equal(part, part2)                          # fixed order: bitwise reproducible
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_relu_folded_into_the_next_projection_equals_the_materialised_path(cuda_device, training):
+    """``QF.BnLinearFn`` (opt-in ``_qot_fuse_bn_projection``): ``relu(norm_l(x)) @ W_{l+1}^T`` with the normalised
+    activations never materialised -- BatchNorm + ReLU applied in the operand load of ``qot_gemm_nt``, recomputed in
+    ``qot_gemm_tn_planes`` for the weight gradient -- against the default path (BnFn, library projections) and the
+    oracle: outputs, every gradient, BatchNorm running statistics (3 layers, C = 32: inner width 128)."""
+    import copy
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    from oracle import sparse as O
+    from helpers import TOL, rel_err
+    torch.manual_seed(0)
+    ref = O.LightpathGNN(5, 32, 3, 1, dropout_p=0.0, num_layers=3)
+    a = q.LightpathGNN(5, 32, 3, 1, dropout_p=0.0, num_layers=3)
+    a.load_state_dict(ref.state_dict(), strict=True)
+    a.to(cuda_device)
+    b = copy.deepcopy(a)
+    a._qot_fuse_bn_projection, b._qot_fuse_bn_projection = True, False
+    batch = S.lightpath_batch(40)
+    dbatch = batch.to(cuda_device)
+    for m in (ref, a, b):
+        m.train(training)
+    outs = []
+    for m, d in ((ref, batch), (a, dbatch), (b, dbatch)):
+        o, lb = m(d)
+        if training:
+            torch.nn.functional.smooth_l1_loss(o, d.y[lb]).backward()
+        outs.append(o.detach().cpu())
+    assert rel_err(outs[1], outs[0]) <= TOL and rel_err(outs[2], outs[0]) <= TOL
+    if training:
+        rp = dict(ref.named_parameters())
+        gmax = max(float(p.grad.abs().max()) for p in rp.values())
+        for name, p in a.named_parameters():
+            floor = gmax if name.endswith("conv1.bias") or name.endswith("conv2.bias") or name.endswith("conv3.bias") else 1e-3 * gmax
+            e = float((p.grad.cpu() - rp[name].grad).abs().max() / max(float(rp[name].grad.abs().max()), floor))
+            assert e <= TOL, (name, e)
+        for k, v in ref.state_dict().items():
+            if "running" in k:
+                assert rel_err(a.state_dict()[k].cpu(), v) <= TOL, k
