@@ -49,8 +49,6 @@ SIGNATURES = {
                                  _p, _f, _f, _u64, _p, _p, _p, _int, _i64, _p, _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _i64, _p, _i64, _int,
                                  _p]),
-    "qot_tconv_wedge_workspace_floats": (_sz, [_int, _int]),
-    "qot_tconv_wedge_grad": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
                                 _int, _f, _f, _u64, _p, _p]),

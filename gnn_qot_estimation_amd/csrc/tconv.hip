@@ -492,42 +492,6 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_kernel(
     }
 }
 
-// grad of lin_edge.weight [H, D]:  gWe[c,d] = sum_i ( q_i[c]/sqrt(H) * pds_i[d] + g_i[c] * pal_i[d] ).
-// A [H x N] x [N x D] reduction with a 256-float output: library GEMMs run it without split-K
-// (250 us per call at N = 102400); here each block folds a row slice (thread = (channel, row
-// phase)), partials[blk, H*D] are then summed in a fixed order by the last kernel.
-template <int H, int D>
-__global__ __launch_bounds__(256) void tconv_wedge_partial_kernel(
-    const float* __restrict__ q, int ld, const int32_t* __restrict__ rowmap, const float* __restrict__ g, int ld_go,
-    const float* __restrict__ pds, const float* __restrict__ pal, float* __restrict__ partials, int64_t N) {
-    constexpr int PH = 256 / H;                 // row phases per block
-    __shared__ float red[256 * D];
-    const int c = threadIdx.x % H, ph = threadIdx.x / H;
-    const float rs = rsqrtf((float)H);
-    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per;
-    const int64_t r1 = (r0 + per < N) ? r0 + per : N;
-    float acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.f;
-    for (int64_t i = r0 + ph; i < r1; i += PH) {
-        const float qv = q[(rowmap ? (int64_t)rowmap[i] : i) * ld + c] * rs, gv = g[i * ld_go + c];
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = fmaf(qv, pds[i * D + d], fmaf(gv, pal[i * D + d], acc[d]));
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) red[threadIdx.x * D + d] = acc[d];
-    __syncthreads();
-    if (threadIdx.x < H) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            float s = 0.f;
-            for (int p = 0; p < PH; ++p) s += red[(p * H + threadIdx.x) * D + d];
-            partials[(int64_t)blockIdx.x * H * D + threadIdx.x * D + d] = s;
-        }
-    }
-}
-
 __global__ void partial_sum_kernel(const float* __restrict__ partials, int nblk, int n, float* __restrict__ out) {
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per output
     if (t >= n) return;
@@ -586,26 +550,6 @@ constexpr int kWedgeGroup = 128;
 }  // namespace qot
 
 using namespace qot;
-
-extern "C" size_t qot_tconv_wedge_workspace_floats(int H, int D) {
-    return (size_t)kWedgeBlocks * (size_t)(H > 0 ? H : 0) * (size_t)(D > 0 ? D : 0);
-}
-
-extern "C" int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowmap, const float* grad_out,
-                                    const float* pds, const float* pal, float* grad_w_edge, float* workspace,
-                                    int64_t N, int H, int D, qot_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (N <= 0 || !q || !grad_out || !pds || !pal || !grad_w_edge || !workspace) return QOT_ERR_BADARG;
-    int blocks = kWedgeBlocks;
-    if (N < blocks * 8) blocks = (int)((N + 7) / 8);
-    QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
-        tconv_wedge_partial_kernel<kH, kD><<<blocks, 256, 0, stream>>>(q, ld, rowmap, grad_out, H, pds, pal, workspace, N);
-    }));
-    QOT_LAUNCH_CHECK();
-    partial_sum_kernel<<<grid_for(H * D, 4), 256, 0, stream>>>(workspace, blocks, H * D, grad_w_edge);
-    QOT_LAUNCH_CHECK();
-    return QOT_OK;
-}
 
 extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                              const float* edge_attr, const float* w_edge, const int32_t* rowptr,

@@ -134,7 +134,7 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
  * itself, so grad_skip then holds the gradient wrt the conv output -- pass IT (ld_go = ld_g) to
  * qot_tconv_bwd_src.  grad_w_edge != NULL: grad of lin_edge.weight [H,D] is produced as well
  * (fixed-order block partials; workspace qot_tconv_bwd_dst_workspace_floats(N,H,D) floats),
- * replacing qot_tconv_wedge_grad.
+ * in the same launch.
  * Tile mode (grad_part != NULL; table mode with node_ids == arange(tile_n) for each of the tile_B graphs,
  * N = tile_n * tile_B): a workgroup takes node r of RPB = qot_tconv_rows_per_block(H) consecutive graphs and pre-reduces the
  * table gradient over them: grad_part[ceil(tile_B/RPB), tile_n, 4H] receives the partial sums of
@@ -163,13 +163,6 @@ int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, 
                       const int32_t* pos_t, const int32_t* qmap_t, float* grad_k, float* grad_v,
                       int ld_g, int tile_n, int64_t tile_B, float* grad_part, int64_t N, int H,
                       qot_stream_t stream);
-
-/* grad of lin_edge.weight: gWe[H,D] = (q/sqrt(H))^T pds + grad_out^T pal  (deterministic two-stage
- * column reduction; workspace: qot_tconv_wedge_workspace_floats(H, D) floats). */
-size_t qot_tconv_wedge_workspace_floats(int H, int D);
-int qot_tconv_wedge_grad(const float* q, int ld, const int32_t* rowmap, const float* grad_out,
-                         const float* pds, const float* pal, float* grad_w_edge, float* workspace,
-                         int64_t N, int H, int D, qot_stream_t stream);
 
 /* ---- NNConv (aggr = mean), factorised ----------------------------------------------
  * h_e = relu(W1 ea_e + b1) in R^K, K = 2D.  Builds the GEMM operand
