@@ -43,9 +43,13 @@ __global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict
 }
 
 // Forward.  Every workgroup walks a contiguous chunk of destinations (slot s takes rows r0+s, r0+s+RPB, ...), two
-// in-edges in flight per lane group.  bn_partials != NULL: per-workgroup column sums of (out - bias) and its square
-// land in partials[blk][2][HC] -- the BatchNorm that follows (lightpath_training/models.py:31) gets its batch
-// statistics without another pass over the [N, 4C] matrix (shift = bias keeps the sums centred).
+// in-edges in flight per lane group.  bn_partials != NULL: per-workgroup column (mean, M2 = sum of squared deviations) of
+// out - bias land in partials[blk][2][HC] -- the BatchNorm that follows (lightpath_training/models.py:31) gets its batch
+// statistics without another pass over the [N, 4C] matrix.  Every lane accumulates relative to the FIRST value it sees
+// (a data value: sums of x - x0 and (x - x0)^2 do not cancel however far the column's mean is from zero or from the
+// bias), lanes and workgroups are merged with Chan's pairwise formula in a fixed order (qot_bn_stats_from_partials).
+// (r02 kept sums of (out - bias) and its square: for a channel with |mean - bias| >> std -- behind a ReLU, or large
+// activations -- E[d^2] - E[d]^2 lost the variance's leading bits.)
 template <int HEADS, int C>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ a_src, const float* __restrict__ a_dst,
@@ -62,14 +66,15 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
     const int64_t r0 = (int64_t)blk * chunk;
     const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
     int hh[G::NV];
-    float4 bz[G::NV], s1[G::NV], s2[G::NV];
+    float4 bz[G::NV], s1[G::NV], s2[G::NV], d0[G::NV];
 #pragma unroll
     for (int v = 0; v < G::NV; ++v) {
         hh[v] = (4 * (sub + G::TPR * v)) / C;
         bz[v] = ld4(bias + 4 * (sub + G::TPR * v));
-        s1[v] = f4zero(); s2[v] = f4zero();
+        s1[v] = f4zero(); s2[v] = f4zero(); d0[v] = f4zero();
     }
-    for (int64_t i = r0 + slot; i < r1; i += G::RPB) {
+    int nrows = 0;
+    for (int64_t i = r0 + slot; i < r1; i += G::RPB, ++nrows) {
         float ad[G::NV], m[G::NV], l[G::NV];
         float4 acc[G::NV];
 #pragma unroll
@@ -118,27 +123,48 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
             const float denom = l[v] + 1e-16f;
             const float4 d = scale4(1.0f / denom, acc[v]);            // out - bias
             st4(out + i * G::HC + c, add4(d, bz[v]));
-            s1[v] = add4(s1[v], d);
-            s2[v] = make_float4(fmaf(d.x, d.x, s2[v].x), fmaf(d.y, d.y, s2[v].y), fmaf(d.z, d.z, s2[v].z), fmaf(d.w, d.w, s2[v].w));
+            if (nrows == 0) d0[v] = d;
+            const float4 e = sub4(d, d0[v]);
+            s1[v] = add4(s1[v], e);
+            s2[v] = make_float4(fmaf(e.x, e.x, s2[v].x), fmaf(e.y, e.y, s2[v].y), fmaf(e.z, e.z, s2[v].z), fmaf(e.w, e.w, s2[v].w));
             if (c % C == 0) {
                 stats[(i * HEADS + hh[v]) * 2] = (beg < end) ? m[v] : 0.f;
                 stats[(i * HEADS + hh[v]) * 2 + 1] = denom;
             }
         }
     }
-    if (bn_partials) {          // fixed order: slots 0..RPB-1 of this workgroup, then the workgroups in bn_finalize
+    if (bn_partials) {          // fixed order: slots 0..RPB-1 of this workgroup (Chan merges), then the workgroups
+        __shared__ int rcnt[256];
+        // this slot's (count, mean, M2) per column from its shifted sums
+        const float fn = (float)nrows, rn = nrows > 0 ? 1.0f / fn : 0.f;
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
+            const float4 mu = make_float4(fmaf(s1[v].x, rn, d0[v].x), fmaf(s1[v].y, rn, d0[v].y), fmaf(s1[v].z, rn, d0[v].z),
+                                          fmaf(s1[v].w, rn, d0[v].w));
+            const float4 m2 = make_float4(fmaxf(s2[v].x - s1[v].x * s1[v].x * rn, 0.f), fmaxf(s2[v].y - s1[v].y * s1[v].y * rn, 0.f),
+                                          fmaxf(s2[v].z - s1[v].z * s1[v].z * rn, 0.f), fmaxf(s2[v].w - s1[v].w * s1[v].w * rn, 0.f));
             __syncthreads();
-            red1[threadIdx.x] = s1[v];
-            red2[threadIdx.x] = s2[v];
+            red1[threadIdx.x] = mu;
+            red2[threadIdx.x] = m2;
+            rcnt[threadIdx.x] = nrows;
             __syncthreads();
             if (slot == 0) {
-                float4 a = red1[sub], b = red2[sub];
-                for (int k = 1; k < G::RPB; ++k) { a = add4(a, red1[k * G::TPR + sub]); b = add4(b, red2[k * G::TPR + sub]); }
+                float4 ma = red1[sub], qa = red2[sub];
+                float na = (float)rcnt[sub];
+                for (int k = 1; k < G::RPB; ++k) {
+                    const float nb = (float)rcnt[k * G::TPR + sub];
+                    if (nb == 0.f) continue;
+                    const float4 mb = red1[k * G::TPR + sub], qb = red2[k * G::TPR + sub];
+                    const float nn = na + nb, fb = nb / nn, w = na * fb;       // w = na nb / (na + nb)
+                    const float4 dl = sub4(mb, ma);
+                    ma = make_float4(fmaf(dl.x, fb, ma.x), fmaf(dl.y, fb, ma.y), fmaf(dl.z, fb, ma.z), fmaf(dl.w, fb, ma.w));
+                    qa = make_float4(qa.x + qb.x + dl.x * dl.x * w, qa.y + qb.y + dl.y * dl.y * w, qa.z + qb.z + dl.z * dl.z * w,
+                                     qa.w + qb.w + dl.w * dl.w * w);
+                    na = nn;
+                }
                 const int c = 4 * (sub + G::TPR * v);
-                st4(bn_partials + ((int64_t)blk * 2) * G::HC + c, a);
-                st4(bn_partials + ((int64_t)blk * 2 + 1) * G::HC + c, b);
+                st4(bn_partials + ((int64_t)blk * 2) * G::HC + c, ma);
+                st4(bn_partials + ((int64_t)blk * 2 + 1) * G::HC + c, qa);
             }
         }
     }
@@ -344,6 +370,14 @@ static int gat_blocks_for(int64_t N) {
 
 extern "C" size_t qot_gat_bn_partials_floats(int64_t N, int heads, int C) {
     return (size_t)2048 * 2 * (size_t)(heads * C);
+}
+
+// rows per workgroup of qot_gat_fwd's chunked walk (workgroup b holds rows [b * chunk, min((b + 1) * chunk, N)))
+extern "C" int64_t qot_gat_chunk_rows(int64_t N, int heads, int C) {
+    int64_t grid = 0;
+    QOT_DISPATCH_GAT(heads, C, { grid = gat_blocks_for<kC>(N); using G = GatCfg<4, kC>;
+                                 return ((N + grid - 1) / grid + G::RPB - 1) / G::RPB * G::RPB; });
+    return 0;
 }
 
 // number of workgroups qot_gat_fwd / qot_gat_att_grad launch = rows of their partials buffers

@@ -236,6 +236,46 @@ __global__ void bn_finalize_stats_kernel(const float* __restrict__ x, const floa
     }
 }
 
+// Statistics from per-workgroup (mean, M2) pairs of x - shift (GATConv's epilogue): workgroup b holds rows
+// [b * chunk, min((b + 1) * chunk, N)).  mean = sum n_b mean_b / N; M2 = sum (M2_b + n_b (mean_b - mean)^2) (Chan's
+// formula for many groups at once), both in fp64 with a fixed lane-strided order: no E[d^2] - E[d]^2 cancellation.
+__global__ void bn_finalize_chan_kernel(const float* __restrict__ shift, const float* __restrict__ partials, int nblk,
+                                        int64_t chunk, int64_t N, int C, float eps, float momentum,
+                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                        float* __restrict__ rvar) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    auto rows_of = [&](int b) -> double {
+        const int64_t r0 = (int64_t)b * chunk;
+        const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
+        return r1 > r0 ? (double)(r1 - r0) : 0.0;
+    };
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += rows_of(b) * (double)partials[((int64_t)b * 2) * C + c];
+    const double mu = wave_sum_f64(s) / (double)N;
+    double q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        const double nb = rows_of(b);
+        if (nb > 0.0) {
+            const double d = (double)partials[((int64_t)b * 2) * C + c] - mu;
+            q += (double)partials[((int64_t)b * 2 + 1) * C + c] + nb * d * d;
+        }
+    }
+    q = wave_sum_f64(q);
+    if (lane) return;
+    const double dn = (double)N;
+    const double var = q / dn;
+    const double m = (double)shift[c] + mu;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = (N > 1) ? var * dn / (dn - 1.0) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * m);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+}
+
 __global__ void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nblk, int C,
                                        float* __restrict__ gw, float* __restrict__ gb) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -751,13 +791,13 @@ extern "C" int qot_bn_stats(const float* x, int64_t N, int C, float eps, float m
 // Batch statistics from per-workgroup column partials [nblk][2][C] of (x - shift), (x - shift)^2 produced by the
 // kernel that wrote x (qot_gat_fwd with bn_partials): mean / rstd / running statistics as qot_bn_stats, without
 // another pass over x.
-extern "C" int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t N, int C,
-                                          float eps, float momentum, float* mean, float* rstd, float* running_mean,
-                                          float* running_var, qot_stream_t stream_) {
+extern "C" int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t chunk_rows,
+                                          int64_t N, int C, float eps, float momentum, float* mean, float* rstd,
+                                          float* running_mean, float* running_var, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (N <= 0 || C <= 0 || nblk <= 0 || !shift || !partials || !mean || !rstd) return QOT_ERR_BADARG;
-    bn_finalize_stats_kernel<<<grid_for(C, 4), 256, 0, stream>>>(shift, partials, nblk, N, C, eps, momentum, mean, rstd,
-                                                                 running_mean, running_var);
+    if (N <= 0 || C <= 0 || nblk <= 0 || chunk_rows <= 0 || !shift || !partials || !mean || !rstd) return QOT_ERR_BADARG;
+    bn_finalize_chan_kernel<<<grid_for(C, 4), 256, 0, stream>>>(shift, partials, nblk, chunk_rows, N, C, eps, momentum, mean,
+                                                                rstd, running_mean, running_var);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

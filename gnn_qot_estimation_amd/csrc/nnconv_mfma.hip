@@ -142,58 +142,17 @@ __device__ __forceinline__ void nnconv_gather_tile(
     }
 }
 
-// Diagnostic only (VARIANT 11): the COST SHAPE of a rank-1 (v_mfma_f32_4x4x1) gather without its control flow -- every
-// destination takes exactly four "edges" (rows tile0 + ..., constant h values), 8 destinations per wave, 32 row loads up front,
-// three MFMAs per edge, 9 stores per destination.  Results are meaningless; the time is a lower bound for that design.
-template <int D>
-__device__ __forceinline__ void nnconv_gather_tile_rank1_shape(float* __restrict__ At, const float* __restrict__ x, int ldx,
-                                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                               int64_t tile0, int64_t N, float4& root0, float4& root1) {
-    constexpr int K = 2 * D;
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        const int sub = threadIdx.x & 7, il = threadIdx.x >> 3;
-        const int64_t i = tile0 + il;
-        root0 = f4zero(); root1 = f4zero();
-        if (i < N) { root0 = ld4(x + i * ldx + 8 * sub); root1 = ld4(x + i * ldx + 8 * sub + 4); }
-    }
-    const int64_t i0 = tile0 + 8 * wave;
-    const int e0 = rowptr[i0 < N ? i0 : N];                      // one dependent index round trip, as the real thing
-    const int e_lo = __builtin_amdgcn_readfirstlane(e0);
-    float xr[32];
-#pragma unroll
-    for (int t = 0; t < 32; ++t) {
-        const int j = col[e_lo + t];                             // uniform -> scalar loads
-        xr[t] = x[(int64_t)j * ldx + lane];
-    }
-    const int lane_part = ((2 * (lane >> 3) + (lane & 1)) * 128) + ((lane & 7) >> 1);
-    const int xm = lane >> 3;
-    const float h0 = 0.5f + (lane & 3), h1 = 0.25f, h2 = 1.0f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(h0, xr[4 * d + u], a0, 4, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(h1, xr[4 * d + u], a1, 4, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(h2, xr[4 * d + u], a2, 4, 0, 0);
-        }
-        float* dst = At + lane_part + (((8 * wave + d) ^ xm) << 2);
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk) dst[kk * 2048] = kk < 4 ? a0[kk & 3] : (kk < 8 ? a1[kk & 3] : a2[kk & 3]);
-    }
-}
-
-// diagnostic build only (make DIAG=1, VARIANT 3): per-phase cycle sums, one adder per wave
 #ifdef QOT_DIAG
-__device__ unsigned long long g_stamps[8];
-#define QOT_STAMP(slot)                                                              \
-    if (VARIANT == 3 || VARIANT == 9) {                                              \
-        unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[slot], _t - t_prev);        \
-        t_prev = _t;                                                                 \
-    }
+#define QOT_DIAG_SECTION 1
+#include "diag/nnconv_mfma_diag.inc"
+#undef QOT_DIAG_SECTION
+#endif
+
+// in-kernel cycle stamps: diagnostic build only (make DIAG=1); nothing in the release build
+#ifdef QOT_DIAG
+#define QOT_DIAG_SECTION 2
+#include "diag/nnconv_mfma_diag.inc"
+#undef QOT_DIAG_SECTION
 #else
 #define QOT_STAMP(slot)
 #endif
@@ -224,9 +183,12 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
     unsigned long long t_prev = 0;
     if (VARIANT == 3 || VARIANT == 9) t_prev = __builtin_amdgcn_s_memtime();
 
+#ifdef QOT_DIAG
     if (VARIANT == 11) {
         nnconv_gather_tile_rank1_shape<D>(At, x, ldx, rowptr, col, tile0, N, root0, root1);
-    } else if (VARIANT != 1 && VARIANT != 4 && VARIANT != 5 && VARIANT != 9) {
+    } else
+#endif
+    if (VARIANT != 1 && VARIANT != 4 && VARIANT != 5 && VARIANT != 9) {
         nnconv_gather_tile<D, TRANSPOSE, (VARIANT >= 6 && VARIANT <= 8) ? VARIANT : 0>(At, x, ldx, ea, w1, b1, rowptr, col, eidx, invdeg, tile0, N, root0, root1);
     } else {
         for (int t = threadIdx.x; t < KM * 32; t += 256) At[t] = 1.0f + (float)(t & 7);

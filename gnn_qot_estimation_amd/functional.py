@@ -908,8 +908,9 @@ def _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, 
         if partials is not None and partials[0].numel() > 0 and C % 4 == 0:
             part, shift = partials
             nblk = _lib.load().qot_gat_blocks(N, 4, C // 4)
-            _lib.call("qot_bn_stats_from_partials", P(_f32c(shift)), P(part), nblk, N, C, float(eps), float(momentum),
-                      P(mean), P(rstd), P(running_mean), P(running_var))
+            chunk = _lib.load().qot_gat_chunk_rows(N, 4, C // 4)
+            _lib.call("qot_bn_stats_from_partials", P(_f32c(shift)), P(part), nblk, chunk, N, C, float(eps),
+                      float(momentum), P(mean), P(rstd), P(running_mean), P(running_var))
         else:
             part = torch.empty(_lib.load().qot_bn_partials_floats(N, C), dtype=torch.float32, device=dev)
             _lib.call("qot_bn_stats", P(x), N, C, float(eps), float(momentum), P(mean), P(rstd),

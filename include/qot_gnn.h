@@ -268,7 +268,7 @@ int qot_pool_bwd(const float* grad_out, const int32_t* ptr, const int32_t* batch
  * z[N, heads*C], a_src/a_dst[N, heads]; graph = CSR built with gat_self_loops.
  * out[N, heads*C] (+bias fused); stats[N, heads, 2].
  * qot_gat_logits: a_src[n,h] = <z[n,h,:], att_src[h,:]>, a_dst likewise (App. B.3), one pass over z.
- * qot_gat_fwd, bn_partials != NULL: also writes per-workgroup column sums of (out - bias) and (out - bias)^2,
+ * qot_gat_fwd, bn_partials != NULL: also writes per-workgroup column (mean, sum of squared deviations) of out - bias,
  *   [qot_gat_blocks(N, heads, C)][2][heads*C] floats (buffer of qot_gat_bn_partials_floats), which
  *   qot_bn_stats_from_partials(shift = bias, ...) turns into the batch statistics of the BatchNorm that follows
  *   (lightpath_training/models.py:30-31) without another pass over out. */
@@ -305,11 +305,14 @@ int qot_bn_stats(const float* x, int64_t N, int C, float eps, float momentum, fl
                  float* rstd, float* running_mean, float* running_var, float* partials,
                  qot_stream_t stream);
 /* y = relu?((x - mean) * rstd * w + b) */
-/* batch statistics from column partials [nblk][2][C] of (x - shift), (x - shift)^2 written by the producer of x
- * (qot_gat_fwd): same results as qot_bn_stats without reading x again. */
-int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t N, int C, float eps,
-                               float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
-                               qot_stream_t stream);
+/* batch statistics from per-workgroup column (mean, M2 = sum of squared deviations) pairs [nblk][2][C] of x - shift
+ * written by the producer of x (qot_gat_fwd: workgroup b holds rows [b * chunk_rows, min((b + 1) * chunk_rows, N)),
+ * chunk_rows = qot_gat_chunk_rows(N, heads, C)), merged with Chan's formula in fp64: same results as qot_bn_stats
+ * without reading x again, and no E[d^2] - E[d]^2 cancellation for channels whose mean is far from the shift. */
+int64_t qot_gat_chunk_rows(int64_t N, int heads, int C);
+int qot_bn_stats_from_partials(const float* shift, const float* partials, int nblk, int64_t chunk_rows, int64_t N, int C,
+                               float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                               float* running_var, qot_stream_t stream);
 int qot_bn_apply(const float* x, const float* mean, const float* rstd, const float* w,
                  const float* b, float* y, int64_t N, int C, int relu, qot_stream_t stream);
 /* train-mode backward: needs column sums first (qot_bn_bwd_reduce -> gw[C], gb[C]), then

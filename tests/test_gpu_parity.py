@@ -1079,3 +1079,37 @@ def test_forward_loss_equals_forward_then_criterion(cuda_device, H, p):
     assert abs(lb - float(torch.nn.functional.smooth_l1_loss(ob, y))) <= 1e-6
     for x_, y_ in zip(pa, pb):
         assert torch.equal(x_, y_)
+
+
+def test_batchnorm_statistics_from_gat_partials_survive_large_offsets(cuda_device):
+    """the statistics BatchNorm takes from the GATConv epilogue's partials (no second pass over ``[N, 4C]``) must
+    not lose the variance of a channel whose mean is far from the shift (the conv bias): channels with mean ~ 1e2 and
+    std ~ 1e-1 (behind a ReLU, or large activations).  Per-lane sums are now taken relative to a data value and merged
+    with Chan's formula; compared with the two-pass kernel (``qot_bn_stats``) and with fp64."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import functional as QF, synthetic as S
+    from gnn_qot_estimation_amd.graph import graph_index_for
+    torch.manual_seed(0)
+    dev = cuda_device
+    batch = S.lightpath_batch(300).to(dev)
+    N, heads, C = batch.num_nodes, 4, 32
+    z = torch.randn(N, heads * C, device=dev) * 0.1
+    z[:, 0::7] += 100.0                      # every 7th channel: mean 1e2, std 1e-1
+    z[:, 3::11] -= 40.0
+    conv = q.GATConv(5, C, heads=4).to(dev)
+    graph = graph_index_for(batch, N, gat_self_loops=True)
+    out, part = QF.GatFn.apply(z, conv.att_src, conv.att_dst, conv.bias, graph, 0.2, True)
+    w, b = torch.ones(heads * C, device=dev), torch.zeros(heads * C, device=dev)
+    res = {}
+    for name, partials in (("partials", (part, conv.bias)), ("two_pass", None)):
+        rm, rv = torch.zeros(heads * C, device=dev), torch.ones(heads * C, device=dev)
+        y = QF.BnFn.apply(out.detach(), w, b, rm, rv, True, 0.1, 1e-5, False, False, partials)
+        res[name] = (y, rm, rv)
+    o64 = out.detach().double()
+    mean64, var64 = o64.mean(0), o64.var(0, unbiased=False)
+    y64 = (o64 - mean64) / torch.sqrt(var64 + 1e-5)
+    rv64 = 0.9 + 0.1 * o64.var(0, unbiased=True)
+    for name, (y, rm, rv) in res.items():
+        assert float((rm.double() - 0.1 * mean64).abs().max()) <= 1e-5 * float(mean64.abs().max()), name
+        assert float(((rv.double() - rv64) / rv64).abs().max()) <= 1e-4, (name, float(((rv.double() - rv64) / rv64).abs().max()))
+        assert float((y.double() - y64).abs().max()) <= 2e-3, (name, float((y.double() - y64).abs().max()))
