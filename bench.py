@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)       # ~30 ms: the part needs ~12 ms of load to reach its clock
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--steps-per-graph", type=int, default=4,
+                    help="train steps captured into one HIP graph at N=1 (a replay costs ~8 us of launch gap on this "
+                         "part whatever the graph holds; with an exchange step between backward and update -- N>1 -- it is 1)")
     ap.add_argument("--cpu-sample-graphs", type=int, default=64)
     ap.add_argument("--no-lightpath", action="store_true", help="skip the separate LightpathGNN (configs[2]) measurement")
     ap.add_argument("--lightpath-steps", type=int, default=10)
@@ -69,7 +72,7 @@ def build_model(device):
 class TrainStep:
     """zero_grad -> forward -> SmoothL1 -> backward -> all-reduce -> SGD, eager or HIP-graph."""
 
-    def __init__(self, model, batch, world, use_graph):
+    def __init__(self, model, batch, world, use_graph, steps_per_graph=1):
         from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
         global QF
         from gnn_qot_estimation_amd import functional as QF
@@ -81,6 +84,8 @@ class TrainStep:
         self.loss = torch.zeros((), device=batch.y.device)
         self.graph_fb = None
         self.graph_opt = None
+        self.graph_multi = None              # steps_per_graph whole steps in one graph (N = 1)
+        self.spg = max(1, int(steps_per_graph)) if world == 1 else 1
         self.use_graph = use_graph
 
     def _fwd_bwd(self):
@@ -118,6 +123,12 @@ class TrainStep:
             with torch.cuda.graph(self.graph_fb):
                 self._fwd_bwd()
                 self._update()
+            if self.spg > 1:                 # several whole steps per replay: every step still runs every kernel
+                self.graph_multi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_multi, pool=self.graph_fb.pool()):
+                    for _ in range(self.spg):
+                        self._fwd_bwd()
+                        self._update()
             return
         with torch.cuda.graph(self.graph_fb):
             self._fwd_bwd()
@@ -133,6 +144,15 @@ class TrainStep:
             if self.graph_opt is not None:
                 self.flat.all_reduce_grads()
                 self.graph_opt.replay()
+
+    def run(self, n):
+        """``n`` train steps: replays of the multi-step graph, the remainder step by step."""
+        if self.graph_multi is not None:
+            while n >= self.spg:
+                self.graph_multi.replay()
+                n -= self.spg
+        for _ in range(n):
+            self()
 
 
 def event_time_ms(fn, iters=20, warm=3, settle=False):
@@ -421,7 +441,7 @@ def main():
 
     batch = make_batch(rank, device)
     model = build_model(device)
-    step = TrainStep(model, batch, world, use_graph=not args.no_graph)
+    step = TrainStep(model, batch, world, use_graph=not args.no_graph, steps_per_graph=args.steps_per_graph)
     if step.use_graph:
         step.capture()
 
@@ -432,13 +452,11 @@ def main():
     # The part needs ~12 ms of load to reach its clock: whatever W the caller asks for, at least 50
     # untimed steps (~30 ms) run before the timed region; the extra ones are reported as config.prime_steps.
     prime_steps = max(0, 50 - args.warmup)
-    for _ in range(prime_steps + args.warmup):
-        step()
+    step.run(prime_steps + args.warmup)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    step.run(args.steps)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -448,13 +466,16 @@ def main():
         dt = float(t.item())
     # SURVEY 8(d) asks for the MEDIAN step time: a second pass of the same K steps with an event between steps (kept out
     # of the timed region above so that `value` stays K back-to-back steps between two synchronisations)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # (an event between replays: with steps_per_graph > 1 a sample is the mean of that many consecutive steps)
+    spg = step.spg if step.graph_multi is not None else 1
+    nsamp = max(1, args.steps // spg)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsamp + 1)]
     evs[0].record()
-    for i in range(args.steps):
-        step()
+    for i in range(nsamp):
+        step.run(spg)
         evs[i + 1].record()
     torch.cuda.synchronize()
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) / spg for i in range(nsamp))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = torch.tensor([median_ms], device=device, dtype=torch.float64)
@@ -483,7 +504,10 @@ def main():
                                    "100-node/400-directed-edge topologies, batch=1024 graphs per GPU, dropout 0.5, "
                                    "SGD momentum 0.9, SmoothL1; " + ("graph index cached across steps (BENCH_PREP_OUTSIDE: the HBM-resident, cached-batch loader mode; not the headline)" if os.environ.get("BENCH_PREP_OUTSIDE") else "CSR build included in every step"),
                        "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world, "distinct_graphs_per_gpu": CFG["B"],
-                       "launch": "eager" if step.graph_fb is None else "hip-graph replay (fwd+bwd, optimizer)",
+                       "launch": "eager" if step.graph_fb is None else (
+                           f"hip-graph replay, {step.spg} whole steps (fwd+bwd+optimizer each) per graph" if step.graph_multi is not None
+                           else "hip-graph replay (fwd+bwd, optimizer)"),
+                       "steps_per_graph": step.spg if step.graph_multi is not None else 1,
                        "parallelism": f"dp{world}", "final_loss": loss, "prime_steps": prime_steps,
                        "collective_world_size": dist.get_world_size() if world > 1 else 1,
                        "collective_backend": dist.get_backend() if world > 1 else None,
