@@ -108,6 +108,9 @@ SIGNATURES = {
     "qot_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _p, _p, _p, _p]),
     "qot_gemm_tn_splits": (_int, [_int, _int, _i64]),
     "qot_gemm_tn_planes": (_int, [_p, _i64, _p, _i64, _p, _int, _int, _i64, _int, _p, _p, _p]),
+    "qot_skinny_linear_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "qot_skinny_linear_dw_blocks": (_int, [_i64]),
+    "qot_skinny_linear_dw": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_run_roles": (_int, [_p, _int, _p]),
     "qot_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p]),
     "qot_rows_scatter": (_int, [_p, _p, _p, _i64, _int, _p]),

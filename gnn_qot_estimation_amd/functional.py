@@ -1017,6 +1017,40 @@ def gemm_ok(k: int, n: int) -> bool:
     return k % 32 == 0 and n % 4 == 0 and k >= 32
 
 
+class SkinnyLinearFn(torch.autograd.Function):
+    """``x @ W^T`` for a handful of input features (GATConv's first-layer ``lin``, ``in_channels`` = 5): a bandwidth
+    kernel each way (``csrc/skinny.hip``) instead of padded library GEMMs.  ``x`` (the raw node features) gets no
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        N, F = x.shape
+        C = weight.shape[0]
+        out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        _lib.call("qot_skinny_linear_fwd", P(x), P(weight), P(out), N, F, C)
+        ctx.save_for_backward(x)
+        ctx.dims = (N, F, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, F, C = ctx.dims
+        g = _f32c(g)
+        nblk = _lib.load().qot_skinny_linear_dw_blocks(N)
+        part = torch.empty(nblk, C * F, dtype=torch.float32, device=g.device)
+        _lib.call("qot_skinny_linear_dw", P(g), P(x), P(part), N, F, C)
+        gw = torch.empty(C * F, dtype=torch.float32, device=g.device)
+        _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, gw), (nblk, C * F, 0))])
+        return None, gw.view(C, F)
+
+
+def skinny_ok(f: int, c: int) -> bool:
+    return 1 <= f <= 8 and c % 4 == 0 and 4 <= c <= 1024 and (256 // (c // 4)) * c * f * 4 <= 64 * 1024
+
+
 class GemmFn(torch.autograd.Function):
     """``x @ W^T`` (no bias) for GATConv's projection.  Forward and grad_x go to the library (measured at cfg3's shape,
     ``tools/bench_gemm.py``: 135 TFLOP/s there against 110 for ``qot_gemm_nt``); the weight gradient ``g^T x`` -- inner

@@ -162,8 +162,11 @@ class GATConv(nn.Module):
     def project(self, x):
         """``z = x W^T`` (``lin``, no bias): own MFMA kernel where the inner width allows (``csrc/gemm.hip``), the library
         for the first layer's handful of input features."""
-        if x.is_cuda and x.dtype == torch.float32 and QF.gemm_ok(x.shape[1], self.lin.out_features) and x.shape[0] > 0:
-            return QF.GemmFn.apply(x, self.lin.weight)
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 0:
+            if QF.gemm_ok(x.shape[1], self.lin.out_features):
+                return QF.GemmFn.apply(x, self.lin.weight)
+            if QF.skinny_ok(x.shape[1], self.lin.out_features) and not x.requires_grad:
+                return QF.SkinnyLinearFn.apply(x, self.lin.weight)     # first layer: F = 5 raw node features
         return self.lin(x)
 
     def attend(self, z, graph: GraphIndex, bn_stats: bool = False):

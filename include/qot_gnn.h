@@ -441,6 +441,13 @@ int qot_gemm_tn_splits(int M, int N, int64_t K);
 int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int M, int N, int64_t K,
                        int splits, const float* scale, const float* shift, qot_stream_t stream);
 
+/* ---- first-layer projection with a handful of input features (lightpath_training/models.py:13: GATConv(in_channels = 5,
+ * ...).lin): out[N, C] = x[N, F] . w[C, F]^T, F <= 8, C multiple of 4 (<= 1024) -- pure bandwidth; and its weight gradient
+ * g^T x as per-workgroup partials [qot_skinny_linear_dw_blocks(N)][C * F] the caller sums in order (QOT_ROLE_SUM_ROWS). */
+int qot_skinny_linear_fwd(const float* x, const float* w, float* out, int64_t N, int F, int C, qot_stream_t stream);
+int qot_skinny_linear_dw_blocks(int64_t N);
+int qot_skinny_linear_dw(const float* g, const float* x, float* partials, int64_t N, int F, int C, qot_stream_t stream);
+
 /* ---- multi-role launch: several INDEPENDENT small jobs of one train step in ONE kernel launch -------------------
  * The reference's step (topological_training/train.py:109-116) reaches ~60 small torch / PyG kernels around the two
  * convolutions; on this engine the convolutions are a handful of launches and what is left are 4-9 us jobs whose

@@ -93,3 +93,23 @@ def test_bn_relu_folded_into_the_next_projection_equals_the_materialised_path(cu
         for k, v in ref.state_dict().items():
             if "running" in k:
                 assert rel_err(a.state_dict()[k].cpu(), v) <= TOL, k
+
+
+@pytest.mark.parametrize("N,F,C", [(1000, 5, 512), (33, 5, 128), (4097, 8, 32), (7, 1, 1024), (100000, 5, 512)])
+def test_skinny_first_layer_projection_and_weight_gradient(cuda_device, N, F, C):
+    """``QF.SkinnyLinearFn`` (GATConv's first-layer ``lin``: 5 raw node features in, lightpath_training/models.py:13) against
+    fp64: forward and weight gradient; bitwise run to run."""
+    from gnn_qot_estimation_amd import functional as QF
+    torch.manual_seed(0)
+    x = torch.randn(N, F, device=cuda_device)
+    w = torch.randn(C, F, device=cuda_device, requires_grad=True)
+    g = torch.randn(N, C, device=cuda_device)
+    out = QF.SkinnyLinearFn.apply(x, w)
+    out.backward(g)
+    ref = x.double() @ w.detach().double().t()
+    assert _rel(out.detach(), ref) <= 1e-6
+    assert _rel(w.grad, g.double().t() @ x.double()) <= 2e-5
+    g1 = w.grad.clone()
+    w.grad = None
+    QF.SkinnyLinearFn.apply(x, w).backward(g)
+    assert torch.equal(g1, w.grad)
