@@ -768,6 +768,7 @@ class HeadFn(torch.autograd.Function):
         ctx.side = side if fold else None
         if loss is not None:
             ctx.mark_non_differentiable(gout)
+            ctx.set_materialize_grads(False)     # no zeros_like(gout) fill launch for the output that carries no gradient
             return out, gout
         return out
 
@@ -775,6 +776,8 @@ class HeadFn(torch.autograd.Function):
     def backward(ctx, g, _g_gout=None):
         ptr32, w0, w3, pooled, hidden, step, x_in, in_step = ctx.saved_tensors
         N, H, O, B, slope, p, seed = ctx.cfg
+        if g is None:                            # (only with set_materialize_grads(False): no gradient reached `out`)
+            g = torch.zeros(B, O, dtype=torch.float32, device=pooled.device)
         g = _f32c(g)
         dev = g.device
         gx = torch.empty(N, H, dtype=torch.float32, device=dev)

@@ -39,6 +39,8 @@ def run(name, model, batch, loss_fn, steps=10, warm=3):
                ms_per_step=round(dt * 1e3, 3), graphs_per_s=round(batch.num_graphs / dt), loss=round(lv, 5),
                mem_GB=round(torch.cuda.max_memory_allocated() / 2**30, 2))
     print(json.dumps(row), flush=True)
+    del flat, opt
+    torch.cuda.empty_cache()         # the next config must not inherit this one's cached blocks (3 timed steps: allocator churn shows)
     return row
 
 
