@@ -42,6 +42,8 @@ SIGNATURES = {
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),
+    "qot_tconv_fwd_tile": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _i64,
+                                  _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_bwd_dst_workspace_floats": (_sz, [_i64, _int, _int]),
     "qot_tconv_rows_per_block": (_int, [_int]),
     "qot_tconv_bwd_dst_blocks": (_i64, [_i64, _int, _int, _i64]),

@@ -147,6 +147,146 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     }
 }
 
+// Forward, TILE form of table mode (node_ids == arange(tile_n) in each of the tile_B graphs: what the reference's dataset
+// emits, topological_training/dataset.py:78).  A workgroup takes node r of RPB consecutive graphs (the mapping the
+// destination pass of the backward already uses), so all its destinations share ONE query row q_r, and the logits'
+// dense part  <q_i, k_j> / sqrt(H)  is an entry of row r of the n x n matrix  T_q T_k^T  of the projected table: the
+// workgroup computes that row ONCE (n dots of H, spread over its lane groups) into LDS, and an in-edge then costs one LDS
+// lookup instead of a 4H-byte key-row gather, a dot and a lane-group reduction -- the value row is the only row gathered
+// per edge.  Per-edge features stay with the lane that prefetched them (it forms the whole logit; the weighted feature
+// sum is kept per owner lane and reduced once per destination): two broadcasts per edge instead of five.
+// Same arithmetic as tconv_fwd_kernel up to the order of the H-term dot (row-of-S first, then + <We^T q, ea>).
+template <int H, int D>
+__global__ __launch_bounds__(256) void tconv_fwd_tile_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v_,
+    const float* __restrict__ skip, int ld, const float* __restrict__ ea, const float* __restrict__ we,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colf, const int32_t* __restrict__ eid,
+    const int32_t* __restrict__ rowmap, float* __restrict__ out, float* __restrict__ stats, int64_t N, int tile_n,
+    int64_t tile_B, ActParams act) {
+    constexpr int CPL = tconv_cpl(H), NV = CPL / 4;
+    constexpr int TPR = H / CPL;
+    constexpr int RPB = 256 / TPR;
+    extern __shared__ float srow[];                       // [tile_n]: <q_r, k_j> / sqrt(H)
+    const int sub = threadIdx.x % TPR, rloc = threadIdx.x / TPR;
+    const int vb = xcd_block(blockIdx.x, gridDim.x);
+    const int gb = vb / tile_n, r = vb % tile_n;
+    const int64_t gph = (int64_t)gb * RPB + rloc;
+    const bool live = gph < tile_B;
+    const int64_t i = live ? gph * tile_n + r : (int64_t)gb * RPB * tile_n + r;     // dead groups: the first graph's node (reads only)
+    const float rs = rsqrtf((float)H);
+    const int c0 = CPL * sub;
+    const int64_t ri = (int64_t)rowmap[i];
+    float4 qi[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) qi[v] = scale4(rs, ld4(q + ri * ld + c0 + 4 * v));
+    // in-edge range and the first batch's indices / features are requested before the row of S is formed
+    const int beg = live ? rowptr[i] : 0, end = live ? rowptr[i + 1] : 0;
+    // row r of T_q T_k^T: lane group rloc takes j = rloc, rloc + RPB, ...
+    for (int j0 = rloc; j0 < tile_n; j0 += 4 * RPB) {
+        float4 kr[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (j0 + u * RPB < tile_n) ? j0 + u * RPB : j0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) kr[u][v] = ld4(k + (int64_t)j * ld + c0 + 4 * v);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float s = group_sum<TPR>(dotv<NV>(qi, kr[u]));
+            if (sub == 0 && j0 + u * RPB < tile_n) srow[j0 + u * RPB] = s;
+        }
+    }
+    float wl[CPL][D];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
+    float qe[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t = fmaf(comp4(qi[c >> 2], c & 3), wl[c][d], t);
+        qe[d] = group_sum<TPR>(t);
+    }
+    __syncthreads();
+    if (!live) return;
+
+    float m = -INFINITY, l = 0.f;
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f4zero();
+    float aloc[D];                                        // sum_e a_e ea_e over the edges THIS lane prefetched
+#pragma unroll
+    for (int d = 0; d < D; ++d) aloc[d] = 0.f;
+    constexpr int BT = (TPR < 16) ? TPR : 16;
+    for (int base = beg; base < end; base += BT) {
+        const int pme = base + sub;
+        int myj = 0;
+        float mys = 0.f, mye[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) mye[d] = 0.f;
+        if (sub < BT && pme < end) {
+            myj = colf[pme];
+            const int64_t e = eid[pme];
+#pragma unroll
+            for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+            mys = srow[myj];
+#pragma unroll
+            for (int d = 0; d < D; ++d) mys = fmaf(qe[d], mye[d], mys);          // the whole logit of my edge
+        }
+        const int cnt = (end - base < BT) ? end - base : BT;
+        constexpr int UF = 4;
+        for (int u0 = 0; u0 < cnt; u0 += UF) {
+            float4 vr[UF][NV];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int64_t j = __shfl(myj, u0 + u, TPR);
+                const int64_t jr = (u0 + u < cnt) ? j : 0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) vr[u][v] = ld4(v_ + jr * ld + c0 + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                if (u0 + u < cnt) {                           // group-uniform
+                    const float s = __shfl(mys, u0 + u, TPR);
+                    const float mn = fmaxf(m, s);
+                    const float sc = __expf(m - mn);
+                    const float pe = __expf(s - mn);
+                    l = fmaf(l, sc, pe);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] = fma4(pe, vr[u][v], scale4(sc, acc[v]));
+                    const float mine = (sub == u0 + u) ? pe : 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) aloc[d] = fmaf(mine, mye[d], aloc[d] * sc);
+                    m = mn;
+                }
+            }
+        }
+    }
+    float aacc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) aacc[d] = group_sum<TPR>(aloc[d]);
+    const float denom = l + 1e-16f;
+    const float inv = 1.0f / denom;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float4 o = scale4(inv, acc[v]);
+        float oc[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[4 * v + c][d], aacc[d] * inv, oc[c]);
+        const float4 sk = ld4(skip + ri * ld + c0 + 4 * v);
+        st4(out + i * H + c0 + 4 * v, act_apply4(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w), act,
+                                                 (uint64_t)(i * H + c0 + 4 * v) >> 2));
+    }
+    if (sub == 0) {
+        stats[2 * i] = (beg < end) ? m : 0.f;
+        stats[2 * i + 1] = denom;
+    }
+}
+
 // Backward, destination pass.  With a_e the attention weight and da_e = <g_i, v_j + We ea_e>:
 //   delta_i = sum_e a_e da_e ;  ds_e = a_e (da_e - delta_i)
 //   grad_q_i = (sum_e ds_e k_j + We sum_e ds_e ea_e)/sqrt(H)
@@ -563,6 +703,29 @@ extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, con
         constexpr int RPB = tconv_rpb(kH);
         tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
             q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N,
+            make_act(act, act_slope, act_p, act_seed, act_step));
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// Tile form of table mode (see tconv_fwd_tile_kernel): col = table row of every in-edge's source, rowmap = table row of every
+// node, node_ids == arange(tile_n) in each of the tile_B graphs (N = tile_n * tile_B).
+extern "C" int qot_tconv_fwd_tile(const float* q, const float* k, const float* v, const float* skip, int ld,
+                                  const float* edge_attr, const float* w_edge, const int32_t* rowptr,
+                                  const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
+                                  float* stats, int64_t N, int H, int D, int tile_n, int64_t tile_B, int act,
+                                  float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
+                                  qot_stream_t stream) {
+    if (N <= 0 || !rowptr || tile_n <= 0 || tile_B <= 0 || (int64_t)tile_n * tile_B != N) return QOT_ERR_BADARG;
+    if (!q || !k || !v || !skip || !out || !stats || !w_edge || !rowmap || !col || (ld & 3)) return QOT_ERR_BADARG;
+    if (tile_n > 12288) return QOT_ERR_UNSUPPORTED;                 // the row of T_q T_k^T lives in LDS
+    QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
+        constexpr int RPB = tconv_rpb(kH);
+        const int64_t blocks = (int64_t)tile_n * grid_for(tile_B, RPB);
+        if (blocks > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+        tconv_fwd_tile_kernel<kH, kD><<<(int)blocks, 256, (size_t)tile_n * sizeof(float), (hipStream_t)stream>>>(
+            q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N, tile_n, tile_B,
             make_act(act, act_slope, act_p, act_seed, act_step));
     }));
     QOT_LAUNCH_CHECK();

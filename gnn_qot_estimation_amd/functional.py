@@ -264,9 +264,16 @@ class TConvFn(torch.autograd.Function):
         rowmap, colf = (maps[0], maps[1]) if maps is not None else (None, graph.col)
         out = torch.empty(N, H, dtype=torch.float32, device=qkvs.device)
         stats = torch.empty(N, 2, dtype=torch.float32, device=qkvs.device)
-        _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
-                  P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
-                  N, H, D, *_act_args(act))
+        if maps is not None and maps[3][1] <= 12288 and N > 0 and not os.environ.get("QOT_NO_TCONV_TILE"):
+            # tile form: node r of a group of graphs per workgroup, logits' dense part from one row of T_q T_k^T in LDS
+            B_, n_ = maps[3]
+            _lib.call("qot_tconv_fwd_tile", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
+                      P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
+                      N, H, D, int(n_), int(B_), *_act_args(act))
+        else:
+            _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
+                      P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
+                      N, H, D, *_act_args(act))
         ctx.save_for_backward(qkvs, edge_attr, w_edge, stats, out if act is not None else None,
                               act[3] if act is not None else None)
         ctx.graph, ctx.maps = graph, maps

@@ -126,6 +126,15 @@ int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* s
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
                   float* stats, int64_t N, int H, int D, int act, float act_slope, float act_p,
                   uint64_t act_seed, const int64_t* act_step, qot_stream_t stream);
+/* Forward in the TILE form of table mode (rowmap != NULL, node_ids == arange(tile_n) in each of the tile_B graphs, N = tile_n *
+ * tile_B; col = table row of every in-edge's source): a workgroup takes node r of qot_tconv_rows_per_block(H) consecutive
+ * graphs, forms row r of T_q T_k^T / sqrt(H) once in LDS, and an in-edge costs one lookup there instead of a key-row
+ * gather + dot + lane reduction.  Same results as qot_tconv_fwd up to the order of that dot.  tile_n <= 12288. */
+int qot_tconv_fwd_tile(const float* q, const float* k, const float* v, const float* skip, int ld,
+                       const float* edge_attr, const float* w_edge, const int32_t* rowptr, const int32_t* col,
+                       const int32_t* eid, const int32_t* rowmap, float* out, float* stats, int64_t N, int H, int D,
+                       int tile_n, int64_t tile_B, int act, float act_slope, float act_p, uint64_t act_seed,
+                       const int64_t* act_step, qot_stream_t stream);
 /* bwd, destination pass: grad_q[N,H] (ld_g), grad_skip[N,H] (= grad wrt the conv output, same ld_g;
  * may be NULL), per-edge scratch escr[cap,2] = (alpha, dalpha), delta[N], pds[N,D] = sum_e ds_e ea_e,
  * pal[N,D] = sum_e alpha_e ea_e.
