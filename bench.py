@@ -232,6 +232,15 @@ def kernel_table(model, batch):
                                        4 * H, P(ea), P(we), P(g.rowptr), P(g.col), P(g.eid), None, P(out), P(stats), N, H, D,
                                        0, 0.0, 0.0, 0, None),
         4 * N * H * 4 + N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E)
+    # what the replayed step runs in table mode: the tile form (node r of 16 graphs per workgroup) on a projected table
+    n_, B_ = CFG["n"], N // CFG["n"]
+    t4 = f(n_, 4 * H)
+    ids32 = (torch.arange(N, device=dev, dtype=torch.int32) % n_).contiguous()
+    colf = ids32[g.col.long()].contiguous()
+    add("tconv_fwd_tile", lambda: _lib.call("qot_tconv_fwd_tile", off(t4, 0), off(t4, H), off(t4, 2 * H), off(t4, 3 * H), 4 * H,
+                                            P(ea), P(we), P(g.rowptr), P(colf), P(g.eid), P(ids32), P(out), P(stats), N, H, D,
+                                            n_, B_, 0, 0.0, 0.0, 0, None),
+        N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 4 * N + n_ * 4 * H * 4)
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
                                            4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,
                                            off(gq, 0), off(gq, 3 * H), 4 * H, P(escr), P(delta), P(pds), P(pal),
