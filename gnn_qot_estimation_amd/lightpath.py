@@ -110,11 +110,12 @@ class LightpathGNN(nn.Module):
             else:
                 raw, partials = conv.attend(z, graph), None
             width = raw.shape[1]
-            # BatchNorm + ReLU folded into the NEXT projection's operand load (QF.BnLinearFn): opt-in.  It saves the
-            # normalised activations' round trip through HBM, but its product runs on csrc/gemm.hip's NT kernel, which
-            # the library beats by more than that at cfg3's shape.
+            # BatchNorm + ReLU folded into the NEXT projection's operand load (QF.BnLinearFn): the normalised activations are
+            # never written to / read from HBM (one [N, 4C] tensor less resident per layer); the product runs on
+            # csrc/gemm.hip's NT kernel.  Step time at cfg3 equals the library product + separate apply pass within noise
+            # (34.9-35.2 vs 35.0-35.3 ms); QOT_FUSE_BN_PROJECTION=0 selects the latter.
             if (layer < self.num_layers and QF.gemm_ok(width, width) and raw.shape[0] > 0
-                    and getattr(self, "_qot_fuse_bn_projection", os.environ.get("QOT_FUSE_BN_PROJECTION") == "1")):
+                    and getattr(self, "_qot_fuse_bn_projection", os.environ.get("QOT_FUSE_BN_PROJECTION", "1") != "0")):
                 pending = (norm, raw, partials)
             else:
                 x = norm(raw, relu=True, partials=partials)        # BatchNorm + F.relu fused, materialised
