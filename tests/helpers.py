@@ -10,8 +10,4 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-12))
 
 
-def clone_batch(data, device):
-    return data.to(device)
-
-
 TOL = 1e-4  # BASELINE.json north_star: outputs match the reference forward to <=1e-4 rel fp32
