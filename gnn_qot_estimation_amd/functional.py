@@ -270,8 +270,13 @@ class TConvFn(torch.autograd.Function):
         rowmap, colf = (maps[0], maps[1]) if maps is not None else (None, graph.col)
         out = torch.empty(N, H, dtype=torch.float32, device=qkvs.device)
         stats = torch.empty(N, 2, dtype=torch.float32, device=qkvs.device)
-        if maps is not None and maps[3][1] <= 12288 and N > 0 and not os.environ.get("QOT_NO_TCONV_TILE"):
-            # tile form: node r of a group of graphs per workgroup, logits' dense part from one row of T_q T_k^T in LDS
+        # Tile form (node r of a group of graphs per workgroup, the logits' dense part from one row of T_q T_k^T in LDS): the
+        # workgroup pays n dots for that row where the plain form pays one dot per in-edge of its rows_per_block destinations,
+        # so it is taken only while n stays within ~2x of that (cfg2: 100 vs 64; at 1000-node graphs it cost 8x the kernel).
+        rpb_ = _lib.load().qot_tconv_rows_per_block(H)
+        tile_ok = (maps is not None and N > 0 and maps[3][1] <= 2 * rpb_ * max(2, graph.num_edges_in // max(N, 1))
+                   and not os.environ.get("QOT_NO_TCONV_TILE"))
+        if tile_ok:
             B_, n_ = maps[3]
             _lib.call("qot_tconv_fwd_tile", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
                       P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),

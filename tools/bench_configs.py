@@ -67,7 +67,7 @@ if "cfg3" in which:
     run("cfg3: lightpath 65536 graphs, 3-layer C=128", q.LightpathGNN(5, 128, 3, 1, num_layers=3), b, lp_loss, steps=5, warm=2)
 if "cfg4" in which:
     b = S.tile_batch(S.topological_batch(4, 32, n=1000, e=4000), 32).to(dev)   # one GPU's share: 1024 graphs
-    run("cfg4 per-GPU share: 1024 x (1000n/4000e), 3-layer H=128", q.TopologicalGNN(1000, 128, 3, 4, num_layers=3), b, topo_loss, steps=3, warm=1)
+    run("cfg4 per-GPU share: 1024 x (1000n/4000e), 3-layer H=128", q.TopologicalGNN(1000, 128, 3, 4, num_layers=3), b, topo_loss, steps=4, warm=2)
 if "cfg5" in which:
     b = S.tile_batch(S.topological_batch(5, 16, n=1000), 16).to(dev)           # 256 power-law graphs
-    run("cfg5 (256 graphs): power-law max in-degree 64, H=256", q.TopologicalGNN(1000, 256, 3, 4), b, topo_loss, steps=3, warm=1)
+    run("cfg5 (256 graphs): power-law max in-degree 64, H=256", q.TopologicalGNN(1000, 256, 3, 4), b, topo_loss, steps=4, warm=2)

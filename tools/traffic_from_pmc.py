@@ -11,6 +11,8 @@ NAMES = {                      # kernel-name fragment -> bench.py kernel_table k
     "nnconv_mfma64_kernel": "nnconv_fused_fwd",
     "nnconv_gradh64_kernel": "nnconv_gradh_fused",
     "tconv_fwd_kernel": "tconv_fwd",
+    "tconv_fwd_tile_kernel": "tconv_fwd_tile",
+    "roles_kernel": "roles (prologue / epilogue launches, mean)",
     "tconv_bwd_dst_kernel": "tconv_bwd_dst",
     "tconv_bwd_src_kernel": "tconv_bwd_src",
 }
