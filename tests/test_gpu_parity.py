@@ -1113,3 +1113,22 @@ def test_batchnorm_statistics_from_gat_partials_survive_large_offsets(cuda_devic
         assert float((rm.double() - 0.1 * mean64).abs().max()) <= 1e-5 * float(mean64.abs().max()), name
         assert float(((rv.double() - rv64) / rv64).abs().max()) <= 1e-4, (name, float(((rv.double() - rv64) / rv64).abs().max()))
         assert float((y.double() - y64).abs().max()) <= 2e-3, (name, float((y.double() - y64).abs().max()))
+
+
+def test_tile_form_forward_is_taken_only_for_small_graphs(cuda_device, monkeypatch):
+    """The tile form of the TransformerConv forward pays ``n`` dots per workgroup for its row of ``T_q T_k^T``: right at
+    cfg2 (n = 100, 16 destinations x ~4 in-edges per workgroup), 8x the kernel's time at 1000-node graphs (cfg4 / cfg5) --
+    both give the same results, so only the choice of entry point can be tested."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import _lib, synthetic as S
+    calls = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    for n, e, H, want_tile in ((100, 400, 64, True), (1000, 4000, 128, False), (75, 60, 16, True)):
+        calls.clear()
+        batch = S.topological_batch(2, 4, n=n, e=e).to(cuda_device)
+        m = q.TopologicalGNN(n, H, 3, 4, dropout_p=0.0).to(cuda_device).eval()
+        with torch.no_grad():
+            m(batch)
+        assert ("qot_tconv_fwd_tile" in calls) == want_tile, (n, H, calls)
+        assert ("qot_tconv_fwd" in calls) != want_tile
