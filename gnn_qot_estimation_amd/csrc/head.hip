@@ -105,7 +105,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     // 64-step matrix-vector product below was 64 dependent L2 round trips per graph
     __shared__ float w0s[H * H];
     __shared__ float w3s[8 * H];
-    for (int e = t; e < H * H; e += 256) w0s[e] = w0[e];
+    {   // all of this thread's H*H/256 weights requested before the first LDS store (load -> store per trip: that many
+        // dependent round trips at the start of every workgroup)
+        float wv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) wv[e] = w0[t + 256 * e];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) w0s[t + 256 * e] = wv[e];
+    }
     for (int e = t; e < O * H; e += 256) w3s[e] = w3[e];
     // gW0 element e of thread t: row o = (t*PER + e) / H, col a = (t*PER + e) % H
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
@@ -197,6 +204,205 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     if (t < O) part[H * H + H + O * H + t] = ab3;
 }
 
+// ---- the read-out of a TRAIN step in ONE kernel: forward, criterion and backward per graph -------------------------------
+// With the criterion formed in the forward kernel (qot_head_fwd_loss) the head's backward follows its forward at once and
+// reads the same rows again: pool -> Linear -> LeakyReLU -> Dropout -> Linear -> SmoothL1 -> d/d(all of it) -> pool
+// backward (through the producer's activation) is a chain over ONE graph.  A workgroup walks its graphs; a graph's node
+// rows (<= kHeadRowsCap of them) are read from HBM once and stay in LDS for the pool backward, pooled / hidden never leave
+// the workgroup.  Outputs: out, loss_rows, grad_x and the per-workgroup parameter-gradient partials of head_bwd_kernel
+// (same layout, same fixed-order sum afterwards).  Per step at cfg2: one launch and one 26 MB pass less (head_fwd 9.4 +
+// head_bwd 17.4 us before).
+constexpr int kHeadRowsCap = 128;
+
+template <int H>
+__global__ __launch_bounds__(256) void head_train_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ ptr, const float* __restrict__ w0,
+    const float* __restrict__ b0, const float* __restrict__ w3, const float* __restrict__ b3,
+    const float* __restrict__ target, float beta, float inv_n, float* __restrict__ out, float* __restrict__ grad_out,
+    float* __restrict__ loss_rows, float* __restrict__ gx, float* __restrict__ partials, int64_t B, int O, ActParams act,
+    int fold, ActParams in_act) {
+    constexpr int PER = H * H / 256;
+    constexpr int TPR = H / 4, RPB = 256 / TPR;
+    // xs[kHeadRowsCap][H] | w0s[H][H + 1] | w3s[8*H].  W0's rows are padded by one float: the forward product reads
+    // w0s[t][a] with t across lanes -- at a row stride of H floats every lane of a wave hit the same bank (64-way conflict)
+    constexpr int HP = H + 1;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* xs = dyn;
+    float* w0s = dyn + kHeadRowsCap * H;
+    float* w3s = w0s + H * HP;
+    __shared__ float4 cred[256];
+    __shared__ float pp[H];
+    __shared__ float hh[H];
+    __shared__ float gh[H];
+    __shared__ float gp[H];
+    __shared__ float go[8];
+    __shared__ float lrow[8];
+    float4 acs = f4zero();
+    float aw0[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) aw0[e] = 0.f;
+    float ab0 = 0.f, aw3[8], ab3 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw3[e] = 0.f;
+    const int t = threadIdx.x;
+    const int sub = t % TPR, slot = t / TPR;
+    {   // all of this thread's H*H/256 weights requested before the first LDS store (load -> store per trip: that many
+        // dependent round trips at the start of every workgroup)
+        float wv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) wv[e] = w0[t + 256 * e];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) w0s[((t + 256 * e) / H) * HP + (t + 256 * e) % H] = wv[e];
+    }
+    for (int e = t; e < O * H; e += 256) w3s[e] = w3[e];
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const int beg = ptr[b], end = ptr[b + 1];
+        const int cnt = end - beg;
+        const bool in_lds = cnt <= kHeadRowsCap;
+        // ---- pool (rows kept in LDS for the pool backward when they fit)
+        float4 acc = f4zero();
+        if (slot < RPB) {
+            // eight rows requested before the first is used (a use right behind its load keeps one load in flight: written
+            // as load / store / add per row this loop was ~7 dependent round trips per graph)
+            for (int r0 = slot; r0 < cnt; r0 += 8 * RPB) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u * RPB;
+                    v[u] = ld4(x + (int64_t)(beg + (r < cnt ? r : r0)) * H + 4 * sub);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u * RPB;
+                    if (r < cnt) {
+                        if (in_lds) *reinterpret_cast<float4*>(&xs[r * H + 4 * sub]) = v[u];
+                        acc = add4(acc, v[u]);
+                    }
+                }
+            }
+        }
+        cred[t] = acc;
+        __syncthreads();
+        if (t < TPR) {
+            float4 s4 = cred[t];
+            for (int k2 = 1; k2 < RPB; ++k2) s4 = add4(s4, cred[k2 * TPR + t]);
+            s4 = scale4(1.0f / (float)(cnt > 1 ? cnt : 1), s4);
+            pp[4 * t] = s4.x; pp[4 * t + 1] = s4.y; pp[4 * t + 2] = s4.z; pp[4 * t + 3] = s4.w;
+        }
+        __syncthreads();
+        // ---- Linear -> LeakyReLU -> Dropout
+        float hv = 0.f, dact = 0.f;
+        if (t < H) {
+            float v = b0[t];
+#pragma unroll 8
+            for (int a = 0; a < H; ++a) v = fmaf(w0s[t * HP + a], pp[a], v);
+            // d/dpre of dropout(leaky_relu(pre)), from the same draw the forward applies
+            float d = 1.0f;
+            if (act.thr16) {
+                const uint64_t flat = (uint64_t)(b * H + t);
+                const uint64_t z = act_hash64(act.seed, (uint64_t)act.step[0], flat >> 2);
+                const bool keep = ((uint32_t)(z >> (16 * (flat & 3))) & 0xFFFFu) >= act.thr16;
+                d = keep ? act.keep_scale : 0.f;
+            }
+            d *= (v > 0.f) ? 1.0f : act.slope;
+            hv = v * d;                                   // = dropout(leaky_relu(v))
+            dact = d;
+            hh[t] = hv;
+        }
+        __syncthreads();
+        // ---- Linear(H, O), criterion
+        if (t < O) {
+            float v = b3[t];
+            for (int a = 0; a < H; ++a) v = fmaf(w3s[t * H + a], hh[a], v);
+            out[b * O + t] = v;
+            const float df = v - target[b * O + t];
+            const float ad = fabsf(df);
+            float l, g;
+            if (ad < beta) { l = 0.5f * df * df / beta; g = df / beta; }
+            else           { l = ad - 0.5f * beta;      g = df > 0.f ? 1.f : -1.f; }
+            g *= inv_n;
+            grad_out[b * O + t] = g;
+            go[t] = g;
+            lrow[t] = l * inv_n;
+            ab3 += g;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float sl = lrow[0];
+            for (int o = 1; o < O; ++o) sl += lrow[o];
+            loss_rows[b] = sl;
+        }
+        // ---- backward of the two Linear layers
+        if (t < H) {
+            float v = 0.f;
+            for (int o = 0; o < O; ++o) v = fmaf(w3s[o * H + t], go[o], v);
+            const float g1 = v * dact;
+            gh[t] = g1;
+            ab0 += g1;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) if (o < O) aw3[o] = fmaf(go[o], hv, aw3[o]);     // gW3[o, t]
+        }
+        __syncthreads();
+        if (t < H) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int o = 0; o < H; ++o) v = fmaf(w0s[o * HP + t], gh[o], v);
+            gp[t] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = t * PER + e;
+            aw0[e] = fmaf(gh[idx / H], pp[idx % H], aw0[e]);
+        }
+        __syncthreads();
+        // ---- pool backward: every node row of the graph gets gp / count, through the producer's activation when folded
+        const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+        float4 cs = f4zero();
+        if (slot < RPB) {
+            const float4 v = make_float4(gp[4 * sub] * inv, gp[4 * sub + 1] * inv, gp[4 * sub + 2] * inv, gp[4 * sub + 3] * inv);
+            if (!fold) {
+                for (int r = slot; r < cnt; r += RPB) st4(gx + (int64_t)(beg + r) * H + 4 * sub, v);
+            } else {
+                for (int r = slot; r < cnt; r += RPB) {
+                    const int64_t flat = (int64_t)(beg + r) * H + 4 * sub;
+                    const float4 yy = in_lds ? *reinterpret_cast<const float4*>(&xs[r * H + 4 * sub]) : ld4(x + flat);
+                    uint64_t z = 0;
+                    if (in_act.thr16) z = act_hash64(in_act.seed, (uint64_t)in_act.step[0], (uint64_t)flat >> 2);
+                    float vi[4] = {v.x, v.y, v.z, v.w};
+                    const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool keep = in_act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= in_act.thr16) : true;
+                        vi[c] = vi[c] * (keep ? in_act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : in_act.slope);
+                    }
+                    const float4 o4 = make_float4(vi[0], vi[1], vi[2], vi[3]);
+                    st4(gx + flat, o4);
+                    cs = add4(cs, o4);
+                }
+            }
+        }
+        if (fold) {
+            cred[t] = cs;
+            __syncthreads();
+            if (t < TPR) {
+                float4 s4 = cred[t];
+                for (int k2 = 1; k2 < RPB; ++k2) s4 = add4(s4, cred[k2 * TPR + t]);
+                acs = add4(acs, s4);
+            }
+        }
+        __syncthreads();
+    }
+    float* part = partials + (int64_t)blockIdx.x * (H * H + H + O * H + O + (fold ? H : 0));
+    if (fold && t < H / 4) st4(part + H * H + H + O * H + O + 4 * t, acs);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) part[t * PER + e] = aw0[e];
+    if (t < H) {
+        part[H * H + t] = ab0;
+        for (int o = 0; o < O; ++o) part[H * H + H + o * H + t] = aw3[o];
+    }
+    if (t < O) part[H * H + H + O * H + t] = ab3;
+}
+
 // out[t] = sum over the nblk workgroup partials (fixed order).  1024 threads = 64 consecutive outputs x 16 part
 // groups: every load is a 256-B row segment (the one-wave-per-output form read each partial with a stride of
 // n floats: 12.8 us for 9 MB), 8 independent loads in flight per thread, part groups meet in LDS.
@@ -241,6 +447,40 @@ using namespace qot;
         case 128: { constexpr int kH = 128; __VA_ARGS__; } break;     \
         default: return QOT_ERR_UNSUPPORTED;                          \
     }
+
+// The read-out of a train step in one kernel (head_train_kernel): forward + SmoothL1(mean, beta) + backward.  out[B,O],
+// grad_out[B,O] = d loss / d out, loss_rows[B] (the loss is their sum), grad_x[N,H] (wrt the CONV output when fold != 0: x is
+// then y = dropout(leaky_relu(conv)) with the in_* parameters), workspace: the per-workgroup parameter-gradient partials
+// [qot_head_bwd_blocks(B)][H*H + H + O*H + O (+ H)] the caller sums (QOT_ROLE_SUM_ROWS), as qot_head_bwd(grads = NULL).
+extern "C" int qot_head_train(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3,
+                              const float* b3, const float* target, float beta, float* out, float* grad_out,
+                              float* loss_rows, float* grad_x, float* workspace, int64_t B, int H, int O, float slope,
+                              float p, uint64_t seed, const int64_t* step_counter, int fold, float in_slope, float in_p,
+                              uint64_t in_seed, const int64_t* in_step, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B <= 0 || O <= 0 || !(beta > 0.f)) return QOT_ERR_BADARG;
+    if (O > 8) return QOT_ERR_UNSUPPORTED;
+    if (!x || !ptr || !w0 || !b0 || !w3 || !b3 || !target || !out || !grad_out || !loss_rows || !grad_x || !workspace)
+        return QOT_ERR_BADARG;
+    const ActParams ap = make_act(1, slope, p, seed, step_counter);
+    const ActParams in_ap = make_act(fold ? 1 : 0, in_slope, in_p, in_seed, in_step);
+    int blocks = kHeadBwdBlocks;
+    if (B < blocks) blocks = (int)B;
+    const float inv_n = 1.0f / ((float)B * (float)O);
+    QOT_HEAD_H(H, {
+        const size_t lds = (size_t)(kHeadRowsCap * kH + kH * (kH + 1) + 8 * kH) * sizeof(float);
+        static size_t allowed = 48 * 1024;
+        if (lds > allowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_train_kernel<kH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allowed = lds;
+        }
+        head_train_kernel<kH><<<blocks, 256, lds, stream>>>(x, ptr, w0, b0, w3, b3, target, beta, inv_n, out, grad_out,
+                                                            loss_rows, grad_x, workspace, B, O, ap, fold, in_ap);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
 
 extern "C" int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const float* b0,
                                  const float* w3, const float* b3, float* pooled, float* hidden, float* out,

@@ -27,8 +27,18 @@ __device__ __forceinline__ void nnconv_bwd_finalize64_body(const float* __restri
     const int sub = (int)(gt & 15);
     const bool live = t * 4 < elems;
     float4 acc = f4zero();
-    if (live)
-        for (int sidx = sub; sidx < nslabs; sidx += 16) acc = add4(acc, ld4(slabs + (int64_t)sidx * elems + 4 * t));
+    if (live) {
+        // eight slabs requested before the first is added (one load -> wait -> add per trip was 16 dependent round trips)
+        int sidx = sub;
+        for (; sidx + 7 * 16 < nslabs; sidx += 8 * 16) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld4(slabs + (int64_t)(sidx + 16 * u) * elems + 4 * t);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+        }
+        for (; sidx < nslabs; sidx += 16) acc = add4(acc, ld4(slabs + (int64_t)sidx * elems + 4 * t));
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
         acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);

@@ -57,8 +57,19 @@ __device__ __forceinline__ void table_project_bwd_body(const float* __restrict__
     float acc = 0.f, sb = 0.f;
     if (vb < 4 * H) {
         const int c = vb;
-#pragma unroll 4
-        for (int v = ph; v < V; v += PH) {
+        // (eight rows' operands requested before the first product: load -> use per trip serialises the round trips)
+        int v = ph;
+        for (; v + 7 * PH < V; v += 8 * PH) {
+            float gv[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gv[u] = gp[(int64_t)(v + u * PH) * 4 * H + c];
+                tv[u] = table[(int64_t)(v + u * PH) * H + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc = fmaf(gv[u], tv[u], acc); sb += gv[u]; }
+        }
+        for (; v < V; v += PH) {
             const float gv = gp[(int64_t)v * 4 * H + c];
             acc = fmaf(gv, table[(int64_t)v * H + a], acc);
             sb += gv;
@@ -75,10 +86,19 @@ __device__ __forceinline__ void table_project_bwd_body(const float* __restrict__
         const int v = vb - 4 * H;
         for (int c = threadIdx.x; c < 4 * H; c += 256) g[c] = gp[(int64_t)v * 4 * H + c];
         __syncthreads();
-#pragma unroll 4
-        for (int c = ph; c < 4 * H; c += PH) {
-            const int s = c / H, o = c % H;
-            acc = fmaf(g[c], proj_w(p, s)[(int64_t)o * H + a], acc);
+        for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {              // 4H / PH = 16 H / 256 * ... trips: a multiple of 8 for every width
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * PH;
+                const int cc = c < 4 * H ? c : ph;
+                wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * PH;
+                if (c < 4 * H) acc = fmaf(g[c], wv[u], acc);
+            }
         }
         red[threadIdx.x] = acc;
         __syncthreads();

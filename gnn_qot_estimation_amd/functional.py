@@ -763,22 +763,41 @@ class HeadFn(torch.autograd.Function):
         hidden = torch.empty(B, H, dtype=torch.float32, device=dev)
         out = torch.empty(B, O, dtype=torch.float32, device=dev)
         gout = loss_rows = None
+        fold = in_act is not None and side is not None
+        ctx.train_fused = None
         if loss is not None:
-            target, beta, loss_out = loss
+            target, beta, loss_out = loss[:3]
             target = _f32c(target.detach())
             if target.shape != (B, O):
                 raise ValueError(f"target must be [{B}, {O}], got {tuple(target.shape)}")
             gout = torch.empty(B, O, dtype=torch.float32, device=dev)
             loss_rows = torch.empty(B, dtype=torch.float32, device=dev)
+            ctx.loss = (loss_rows, loss_out)
+            if len(loss) > 3 and loss[3] and not os.environ.get("QOT_NO_HEAD_TRAIN"):
+                # train step: forward, criterion AND backward of the read-out in one kernel (the graph's rows are read
+                # once and stay in LDS for the pool backward); backward() only hands the results on
+                nb = H * H + H + O * H + O
+                gx = torch.empty(N, H, dtype=torch.float32, device=dev)
+                ws = torch.empty(_lib.load().qot_head_bwd_workspace_floats(H, O), dtype=torch.float32, device=dev)
+                fa = (1, float(in_act[0]), float(in_act[1] if in_act[3] is not None else 0.0), int(in_act[2]), P(in_act[3])) \
+                    if fold else (0, 0.0, 0.0, 0, None)
+                _lib.call("qot_head_train", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(target), float(beta), P(out), P(gout),
+                          P(loss_rows), P(gx), P(ws), B, H, O, float(slope), float(p if step is not None else 0.0), int(seed),
+                          P(step), *fa)
+                ctx.train_fused = (gx, ws, gout, nb + (H if fold else 0))
+                ctx.cfg = (N, H, O, B, float(slope), float(p if step is not None else 0.0), int(seed))
+                ctx.fold = fold
+                ctx.side = side if fold else None
+                ctx.mark_non_differentiable(gout)
+                ctx.set_materialize_grads(False)
+                return out, gout
             _lib.call("qot_head_fwd_loss", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H,
                       O, float(slope), float(p if step is not None else 0.0), int(seed), P(step), P(target), float(beta),
                       P(gout), P(loss_rows))
-            ctx.loss = (loss_rows, loss_out)
         else:
             _lib.call("qot_head_fwd", P(x), P(ptr32), P(w0), P(b0), P(w3), P(b3), P(pooled), P(hidden), P(out), B, H, O,
                       float(slope), float(p if step is not None else 0.0), int(seed), P(step))
             ctx.loss = None
-        fold = in_act is not None and side is not None
         ctx.save_for_backward(ptr32, w0, w3, pooled, hidden, step, x if fold else None,
                               in_act[3] if fold else None)
         ctx.cfg = (N, H, O, B, float(slope), float(p if step is not None else 0.0), int(seed))
@@ -791,7 +810,36 @@ class HeadFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _backward_train_fused(ctx, g):
+        """The kernel of the forward has already gone backward with ``grad_out = d loss / d out``: valid only for exactly
+        that gradient -- ``out.backward(g)`` with the tensor ``forward_loss`` returned."""
+        gx, ws, gout, ntot = ctx.train_fused
+        N, H, O, B, slope, p, seed = ctx.cfg
+        if g is None or g.data_ptr() != gout.data_ptr() or g.shape != gout.shape:
+            raise RuntimeError("the read-out ran its backward inside forward_loss with the criterion's own gradient: call "
+                               "out.backward(g) with the g forward_loss returned (or use forward() + a criterion)")
+        nb = H * H + H + O * H + O
+        grads = torch.empty(ntot, dtype=torch.float32, device=gx.device)
+        loss_rows, loss_out = ctx.loss
+        roles = [(_lib.ROLE_SUM_ROWS, (ws, grads), (_lib.load().qot_head_bwd_blocks(B), ntot, 0)),
+                 (_lib.ROLE_SUM_ROWS, (loss_rows, loss_out), (B, 1, 0))]
+        if LG.can_defer(*ctx.receivers, ctx.side.get("bias_param") if ctx.fold else None):
+            for r in roles:
+                LG.defer(*r, stage=1)
+        else:
+            _lib.run_roles([_lib.make_role(*r) for r in roles])
+        if ctx.fold:
+            ctx.side["gbias"] = grads[nb:]
+        gw0 = grads[:H * H].view(H, H)
+        gb0 = grads[H * H:H * H + H]
+        gw3 = grads[H * H + H:H * H + H + O * H].view(O, H)
+        gb3 = grads[H * H + H + O * H:H * H + H + O * H + O]
+        return gx, None, gw0, gb0, gw3, gb3, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, g, _g_gout=None):
+        if ctx.train_fused is not None:
+            return HeadFn._backward_train_fused(ctx, g)
         ptr32, w0, w3, pooled, hidden, step, x_in, in_step = ctx.saved_tensors
         N, H, O, B, slope, p, seed = ctx.cfg
         if g is None:                            # (only with set_materialize_grads(False): no gradient reached `out`)

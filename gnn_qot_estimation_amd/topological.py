@@ -192,7 +192,7 @@ class TopologicalGNN(nn.Module):
                 if loss_out is None:
                     loss_out = torch.empty((), dtype=torch.float32, device=x.device)
                 out, gout = QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
-                                            last_act if side is not None else None, side, (target, beta, loss_out))
+                                            last_act if side is not None else None, side, (target, beta, loss_out, True))
                 return out, gout, loss_out
             return QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
                                    last_act if side is not None else None, side)

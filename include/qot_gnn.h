@@ -394,6 +394,17 @@ int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const
                       const float* b3, float* pooled, float* hidden, float* out, int64_t B, int H, int O,
                       float slope, float p, uint64_t seed, const int64_t* step_counter, const float* target,
                       float beta, float* grad_out, float* loss_rows, qot_stream_t stream);
+/* The read-out of a TRAIN step in one kernel: forward + SmoothL1(mean, beta) + backward per graph (a graph's rows are read
+ * once and stay in LDS for the pool backward; pooled / hidden never leave the workgroup).  grad_x[N,H] is the gradient wrt
+ * the CONV output when fold != 0 (x = dropout(leaky_relu(conv)) with the in_* parameters, as qot_head_bwd(x_in)).
+ * workspace: per-workgroup parameter-gradient partials [qot_head_bwd_blocks(B)][H*H + H + O*H + O (+ H when fold)] for the
+ * caller to sum (QOT_ROLE_SUM_ROWS); the loss value is the sum of loss_rows[B].  Replaces {qot_head_fwd_loss, qot_head_bwd}
+ * of a step (topological_training/train.py:111-115). */
+int qot_head_train(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3, const float* b3,
+                   const float* target, float beta, float* out, float* grad_out, float* loss_rows, float* grad_x,
+                   float* workspace, int64_t B, int H, int O, float slope, float p, uint64_t seed,
+                   const int64_t* step_counter, int fold, float in_slope, float in_p, uint64_t in_seed,
+                   const int64_t* in_step, qot_stream_t stream);
 size_t qot_head_bwd_workspace_floats(int H, int O);
 int qot_head_bwd_blocks(int64_t B);
 int qot_head_bwd(const float* grad_out, const float* pooled, const float* hidden, const int32_t* ptr,
