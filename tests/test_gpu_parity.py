@@ -1049,17 +1049,21 @@ def test_launch_groups_off_equals_on(cuda_device, monkeypatch):
             assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1e-3 * gmax)
 
 
-@pytest.mark.parametrize("H,p", [(64, 0.0), (64, 0.5), (32, 0.0), (256, 0.0)])
-def test_forward_loss_equals_forward_then_criterion(cuda_device, H, p):
+@pytest.mark.parametrize("H,p,n,e", [(64, 0.0, 30, 100), (64, 0.5, 30, 100), (32, 0.0, 30, 100), (256, 0.0, 30, 100),
+                                     (128, 0.5, 300, 900), (16, 0.5, 150, 400)])
+def test_forward_loss_equals_forward_then_criterion(cuda_device, H, p, n, e):
     """``TopologicalGNN.forward_loss`` (criterion folded into the read-out head's kernel, loss value summed by the
     backward epilogue) against ``forward`` + ``smooth_l1_loss_and_grad`` + the oracle's ``F.smooth_l1_loss``: same
-    output, loss, d loss / d out and parameter gradients.  H = 256 has no fused head: the fallback path."""
+    output, loss, d loss / d out and parameter gradients.  H = 256 has no fused head: the fallback path.  With a target the
+    read-out runs forward, criterion and backward in ONE kernel (``qot_head_train``: a graph's rows stay in LDS up to 128
+    of them -- the 300- and 150-node cases take the re-read path); passing any other gradient than the one returned
+    must raise."""
     import gnn_qot_estimation_amd as q
     from gnn_qot_estimation_amd import functional as QF, synthetic as S
     torch.manual_seed(2)
-    batch = S.topological_batch(2, 12, n=30, e=100).to(cuda_device)
+    batch = S.topological_batch(2, 12, n=n, e=e).to(cuda_device)
     y = batch.y.view(-1, 3) * 4.0 - 1.5                   # both branches of the Huber function
-    m = q.TopologicalGNN(30, H, 3, 4, dropout_p=p).to(cuda_device).train()
+    m = q.TopologicalGNN(n, H, 3, 4, dropout_p=p).to(cuda_device).train()
     m._qot_seed = 77
     res = []
     for fused in (True, False):
@@ -1074,11 +1078,17 @@ def test_forward_loss_equals_forward_then_criterion(cuda_device, H, p):
         torch.cuda.synchronize()
         res.append((out.detach().clone(), float(loss), g.clone(), [p_.grad.clone() for p_ in m.parameters()]))
     (oa, la, ga, pa), (ob, lb, gb_, pb) = res
-    assert torch.equal(oa, ob) and torch.equal(ga, gb_)
+    assert float((oa - ob).abs().max()) <= 2e-6 * float(ob.abs().max())
+    assert float((ga - gb_).abs().max()) <= 2e-6 * float(gb_.abs().max())
     assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
     assert abs(lb - float(torch.nn.functional.smooth_l1_loss(ob, y))) <= 1e-6
-    for x_, y_ in zip(pa, pb):
-        assert torch.equal(x_, y_)
+    gmax = max(float(y_.abs().max()) for y_ in pb)
+    for x_, y_ in zip(pa, pb):          # the one-kernel read-out rounds dropout(leaky_relu(.)) in another order: 1 ulp
+        assert float((x_ - y_).abs().max()) <= 2e-6 * max(float(y_.abs().max()), 1e-3 * gmax)
+    if H != 256:
+        out, loss, g = m.forward_loss(batch, y)
+        with pytest.raises(RuntimeError, match="forward_loss"):
+            out.backward(torch.ones_like(g))
 
 
 def test_batchnorm_statistics_from_gat_partials_survive_large_offsets(cuda_device):
