@@ -542,7 +542,7 @@ __global__ void nnconv_dw_final_kernel(const float* __restrict__ slabs, int nspl
 // Bp layout (functional.nnconv_gen_gradh_perm_index): pass p (32 input channels, or H when H < 32), 32-column block
 // nb of GA_p (column n = k*CWG + al), group gq of 8 output channels o, lane l, r:
 //   Bp[(((p*NBG + nb)*GH + gq)*64 + l)*4 + r] = W2[(p*CWG + al)*H + o, k],  o = 8 gq + 2r + (l>>5),  n = nb*32 + (l&31)
-constexpr int kEdgeCap = 256;      // per-edge partial dots kept in LDS between channel passes (one segment)
+constexpr int kEdgeCap = 512;      // edges of a tile staged in LDS (the rest is read directly)
 
 template <int H, int D>
 __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
@@ -558,9 +558,15 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
     constexpr int NBG = K * CWG / 32;             // 32-column blocks of GA_p
     constexpr int GH = H / 8;                     // groups of 8 output channels
     constexpr int LDGA = K * CWG + 4;
+    constexpr int EPF = 8;                        // edge slots of a lane group whose source rows are requested ahead
     __shared__ __attribute__((aligned(16))) float Gt[GH * 2 * 32 * 4];
     __shared__ __attribute__((aligned(16))) float GAt[32 * LDGA > 2 * (D + 1) * 256 ? 32 * LDGA : 2 * (D + 1) * 256];
-    __shared__ float pe[(NPG > 1) ? kEdgeCap * 8 : 8];
+    // the tile's first kEdgeCap edges, staged once per tile: source row, local destination row, 1/deg of the
+    // destination, edge features
+    __shared__ int sj[kEdgeCap], sr[kEdgeCap];
+    __shared__ float ssc[kEdgeCap];
+    __shared__ __attribute__((aligned(16))) float sea[kEdgeCap * D];
+    __shared__ int rp_l[36];
     float4* Gt4 = reinterpret_cast<float4*>(Gt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r31 = lane & 31, hi = lane >> 5;
@@ -572,6 +578,54 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) { wrow[d] = (sub < K) ? w1[sub * D + d] : 0.f; aw[d] = 0.f; }
 
+    // One edge of the pass: dots of the destination's GA rows (LDS) with this pass's channels of the source row, the 8
+    // values transposed over the 8 lanes (lane k ends with the total of k), and -- the gradient being LINEAR in the
+    // dots -- the pass's share goes straight into the lane's sums: grad_h[e, k] = [pre_k > 0] / deg * sum over passes,
+    // so no per-edge partial has to wait for the last pass (r02 kept them in LDS, which bounded the edges of a tile
+    // that one MFMA phase could serve: a 600-edge tile of a power-law graph repeated its MFMA phases three times).
+    auto edge = [&](int r, const float (&row)[CPL], const float (&ee)[D], float sc) {
+        float pd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = 0.f;
+            if (k < K) {
+                float ga[CPL];
+                ldv<CPL>(&GAt[r * LDGA + k * CWG + CPL * sub], ga);
+#pragma unroll
+                for (int c_ = 0; c_ < CPL; ++c_) a = fmaf(ga[c_], row[c_], a);
+            }
+            pd[k] = a;
+        }
+        float t4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float keep = (sub & 4) ? pd[m + 4] : pd[m];
+            const float send = (sub & 4) ? pd[m] : pd[m + 4];
+            t4[m] = keep + dpp_move<0x141>(send);
+        }
+        float t2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float keep = (sub & 2) ? t4[m + 2] : t4[m];
+            const float send = (sub & 2) ? t4[m] : t4[m + 2];
+            t2[m] = keep + dpp_move<0x4E>(send);
+        }
+        const float keep = (sub & 1) ? t2[1] : t2[0];
+        const float send = (sub & 1) ? t2[0] : t2[1];
+        const float tot = keep + dpp_move<0xB1>(send);          // k = sub
+        float pre = brow;
+#pragma unroll
+        for (int d = 0; d < D; ++d) pre = fmaf(wrow[d], ee[d], pre);
+        const float gh = (pre > 0.f && sub < K) ? tot * sc : 0.f;
+        ab += gh;
+#pragma unroll
+        for (int d = 0; d < D; ++d) aw[d] = fmaf(gh, ee[d], aw[d]);
+    };
+    auto staged_ee = [&](int s, float (&ee)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ee[d] = sea[s * D + d];
+    };
+
 #pragma unroll 1
     for (int64_t it = 0;; ++it) {
         const int64_t tile = xcd_tile(it, ntiles);
@@ -581,6 +635,8 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
         const int64_t tend = (tile0 + 32 < N) ? tile0 + 32 : N;
         const int e_t0 = rowptr[tile0], e_t1 = rowptr[tend];
         if (e_t0 == e_t1) continue;               // no in-edges in this tile (uniform)
+        const int nt = e_t1 - e_t0;
+        const int ncap = nt < kEdgeCap ? nt : kEdgeCap;
         // g tile -> LDS, fragment-grouped over the output channels o
         for (int gq = sub; gq < GH; gq += 8) {
             float4 g0 = f4zero(), g1 = f4zero();
@@ -588,136 +644,117 @@ __global__ __launch_bounds__(256, 2) void nnconv_gradh_gen_kernel(
             Gt4[at4_slot(gq, 0, il)] = make_float4(g0.x, g0.z, g1.x, g1.z);
             Gt4[at4_slot(gq, 1, il)] = make_float4(g0.y, g0.w, g1.y, g1.w);
         }
-        const float sc = (i < N) ? invdeg[i] : 0.f;
-        int beg = 0, end = 0;
-        if (i < N) { beg = rowptr[i]; end = rowptr[i + 1]; }
-#pragma unroll 1
-        for (int seg0 = e_t0; seg0 < e_t1; seg0 += kEdgeCap) {
-            const int seg1 = seg0 + kEdgeCap;
-            const int sb = beg > seg0 ? beg : seg0, se = end < seg1 ? end : seg1;   // this destination's edges in the segment
-#pragma unroll 1
-            for (int p = 0; p < NPG; ++p) {
-                lds_barrier();            // Gt / pe written; GAt free
-                // GA_p tile on the matrix cores
-                for (int nb = wave; nb < NBG; nb += 4) {
-                    const float4* bp = reinterpret_cast<const float4*>(Bp) + ((int64_t)(p * NBG + nb) * GH) * 64 + lane;
-                    f32x16 c;
+        // ---- stage the tile's edges (r03): every thread one or two edges (coalesced col / edge id, then the features),
+        // every destination marks its slots.  The per-edge work is then dealt EVENLY over the 32 lane groups (slot s ->
+        // group s % 32) whatever the degrees: its results are sums over all lanes (aw, ab), so no lane group has to own a
+        // destination -- a degree-64 row costs what 64 edges cost, not 8 serial batches of dependent loads in every
+        // channel pass, and no group idles behind the longest row of its wave.
+        {
+            int beg = 0, end = 0;
+            float sc_i = 0.f;
+            if (i < N) { beg = rowptr[i]; end = rowptr[i + 1]; sc_i = invdeg[i]; }
+            int ej[kEdgeCap / 256];
+            int64_t ee_[kEdgeCap / 256];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = 0.f;
-                    // weight fragments of chunk ch+1 are requested before the MFMAs of chunk ch issue (loaded right in
-                    // front of their use, every group of 4 MFMAs waited for an L2 round trip)
-                    constexpr int GC = (GH % 4 == 0) ? 4 : 2;
-                    constexpr int NGC = GH / GC;
-                    float4 b0[GC], b1[GC];
+            for (int q = 0; q < kEdgeCap / 256; ++q) {
+                const int s = threadIdx.x + 256 * q;
+                ej[q] = 0; ee_[q] = 0;
+                if (s < ncap) { ej[q] = col[e_t0 + s]; ee_[q] = eidx[e_t0 + s]; }
+            }
+            const int lim = e_t0 + ncap;
+            for (int p = beg + sub; p < end && p < lim; p += 8) { sr[p - e_t0] = il; ssc[p - e_t0] = sc_i; }
+            if (threadIdx.x < 33) rp_l[threadIdx.x] = rowptr[tile0 + threadIdx.x < N ? tile0 + threadIdx.x : N];
 #pragma unroll
-                    for (int v = 0; v < GC; ++v) b0[v] = bp[v * 64];
-#pragma unroll 1
-                    for (int ch = 0; ch < NGC; ch += 2) {
-                        if (ch + 1 < NGC) {
+            for (int q = 0; q < kEdgeCap / 256; ++q) {
+                const int s = threadIdx.x + 256 * q;
+                if (s < ncap) {
+                    sj[s] = ej[q];
 #pragma unroll
-                            for (int v = 0; v < GC; ++v) b1[v] = bp[((ch + 1) * GC + v) * 64];
-                        }
-#pragma unroll
-                        for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, ch * GC + v, hi, r31, b0[v], c);
-                        if (ch + 1 < NGC) {
-                            if (ch + 2 < NGC) {
-#pragma unroll
-                                for (int v = 0; v < GC; ++v) b0[v] = bp[((ch + 2) * GC + v) * 64];
-                            }
-#pragma unroll
-                            for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, (ch + 1) * GC + v, hi, r31, b1[v], c);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        GAt[row * LDGA + nb * 32 + r31] = c[r];
-                    }
-                }
-                lds_barrier();
-                // per-edge dots over this pass's channels
-                if (sb < se) {
-                    float ga[K][CPL];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) ldv<CPL>(&GAt[il * LDGA + k * CWG + CPL * sub], ga[k]);
-                    const int cbase = p * CWG + CPL * sub;
-                    for (int base = sb; base < se; base += 8) {
-                        const int pp = base + sub;
-                        int myj = 0;
-                        float mye[D];
-#pragma unroll
-                        for (int d = 0; d < D; ++d) mye[d] = 0.f;
-                        if (pp < se) {
-                            myj = col[pp];
-                            if (p == NPG - 1) {
-                                const int64_t e = eidx[pp];
-#pragma unroll
-                                for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
-                            }
-                        }
-                        const int cnt = (se - base < 8) ? se - base : 8;
-                        for (int u0 = 0; u0 < cnt; u0 += 4) {
-                            float xr[4][CPL];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int64_t j = __shfl(myj, u0 + u, 8);
-                                ldv<CPL>(x + (u0 + u < cnt ? j : 0) * ldx + cbase, xr[u]);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const bool live = u0 + u < cnt;
-                                float pd[8];
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    float a = 0.f;
-                                    if (k < K) {
-#pragma unroll
-                                        for (int t = 0; t < CPL; ++t) a = fmaf(ga[k < K ? k : 0][t], xr[u][t], a);
-                                    }
-                                    pd[k] = a;
-                                }
-                                // transpose-reduce 8 values over the 8 lanes: lane s ends with the total of value s
-                                float t4[4];
-#pragma unroll
-                                for (int m = 0; m < 4; ++m) {
-                                    const float keep = (sub & 4) ? pd[m + 4] : pd[m];
-                                    const float send = (sub & 4) ? pd[m] : pd[m + 4];
-                                    t4[m] = keep + dpp_move<0x141>(send);
-                                }
-                                float t2[2];
-#pragma unroll
-                                for (int m = 0; m < 2; ++m) {
-                                    const float keep = (sub & 2) ? t4[m + 2] : t4[m];
-                                    const float send = (sub & 2) ? t4[m] : t4[m + 2];
-                                    t2[m] = keep + dpp_move<0x4E>(send);
-                                }
-                                const float keep = (sub & 1) ? t2[1] : t2[0];
-                                const float send = (sub & 1) ? t2[0] : t2[1];
-                                float tot = keep + dpp_move<0xB1>(send);          // k = sub
-                                const int slot = (base + u0 + u - seg0) * 8 + sub;
-                                if (NPG > 1 && live) {
-                                    if (p > 0) tot += pe[slot];
-                                    if (p < NPG - 1) pe[slot] = tot;
-                                }
-                                if (p == NPG - 1) {
-                                    float ee[D];
-#pragma unroll
-                                    for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, 8);
-                                    float pre = brow;
-#pragma unroll
-                                    for (int d = 0; d < D; ++d) pre = fmaf(wrow[d], ee[d], pre);
-                                    const float gh = (live && pre > 0.f && sub < K) ? tot * sc : 0.f;
-                                    ab += gh;
-#pragma unroll
-                                    for (int d = 0; d < D; ++d) aw[d] = fmaf(gh, ee[d], aw[d]);
-                                }
-                            }
-                        }
-                    }
+                    for (int d = 0; d < D; ++d) sea[s * D + d] = ea[ee_[q] * D + d];
                 }
             }
-            lds_barrier();                // pe / GAt are rewritten by the next segment / tile
         }
+        const int mine = (ncap - il + 31) / 32;           // staged slots il, il + 32, ... of this lane group
+#pragma unroll 1
+        for (int p = 0; p < NPG; ++p) {
+            lds_barrier();            // Gt / the staged edges written; GAt free
+            // the group's first source rows for this pass are requested before the MFMA phase and used after it
+            float xr[EPF][CPL];
+            const int cbase = p * CWG + CPL * sub;
+#pragma unroll
+            for (int t = 0; t < EPF; ++t)
+                if (t < mine) ldv<CPL>(x + (int64_t)sj[il + 32 * t] * ldx + cbase, xr[t]);
+            // GA_p tile on the matrix cores
+            for (int nb = wave; nb < NBG; nb += 4) {
+                const float4* bp = reinterpret_cast<const float4*>(Bp) + ((int64_t)(p * NBG + nb) * GH) * 64 + lane;
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                // weight fragments of chunk ch+1 are requested before the MFMAs of chunk ch issue (loaded right in
+                // front of their use, every group of 4 MFMAs waited for an L2 round trip)
+                constexpr int GC = (GH % 4 == 0) ? 4 : 2;
+                constexpr int NGC = GH / GC;
+                float4 b0[GC], b1[GC];
+#pragma unroll
+                for (int v = 0; v < GC; ++v) b0[v] = bp[v * 64];
+#pragma unroll 1
+                for (int ch = 0; ch < NGC; ch += 2) {
+                    if (ch + 1 < NGC) {
+#pragma unroll
+                        for (int v = 0; v < GC; ++v) b1[v] = bp[((ch + 1) * GC + v) * 64];
+                    }
+#pragma unroll
+                    for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, ch * GC + v, hi, r31, b0[v], c);
+                    if (ch + 1 < NGC) {
+                        if (ch + 2 < NGC) {
+#pragma unroll
+                            for (int v = 0; v < GC; ++v) b0[v] = bp[((ch + 2) * GC + v) * 64];
+                        }
+#pragma unroll
+                        for (int v = 0; v < GC; ++v) c = mfma_group(Gt4, (ch + 1) * GC + v, hi, r31, b1[v], c);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    GAt[row * LDGA + nb * 32 + r31] = c[r];
+                }
+            }
+            lds_barrier();
+            // per-edge dots over this pass's channels: the staged slots of this group ...
+#pragma unroll
+            for (int t = 0; t < EPF; ++t) {
+                if (t < mine) {
+                    const int s = il + 32 * t;
+                    float ee[D];
+                    staged_ee(s, ee);
+                    edge(sr[s], xr[t], ee, ssc[s]);
+                }
+            }
+            for (int t = EPF; t < mine; ++t) {            // (more than 256 staged edges in the tile)
+                const int s = il + 32 * t;
+                float row[CPL], ee[D];
+                ldv<CPL>(x + (int64_t)sj[s] * ldx + cbase, row);
+                staged_ee(s, ee);
+                edge(sr[s], row, ee, ssc[s]);
+            }
+            // ... and what the tile has beyond the staged ones (a hub's tile): straight from memory, destination by
+            // bisection of the tile's row pointers
+            for (int s = kEdgeCap + il; s < nt; s += 32) {
+                const int pp = e_t0 + s;
+                int lo = 0;
+#pragma unroll
+                for (int st = 16; st > 0; st >>= 1)
+                    if (rp_l[lo + st] <= pp) lo += st;
+                const int64_t e = eidx[pp];
+                float row[CPL], ee[D];
+                ldv<CPL>(x + (int64_t)col[pp] * ldx + cbase, row);
+#pragma unroll
+                for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+                edge(lo, row, ee, invdeg[tile0 + lo]);
+            }
+        }
+        lds_barrier();                // GAt / the staged edges are rewritten by the next tile
     }
     // block partial: sum the 32 lane groups (fixed order) -> partials[blk][K*(D+1)]
     lds_barrier();

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 def _case(case, H, dev):
     g = torch.Generator().manual_seed(17 + H)
     D = 2 if case == "edge_dim2" else 4
-    if case == "hub":
+    if case in ("hub", "big_hub"):
         N = 500 + 13
-        src = torch.randint(0, N, (300,), generator=g)
+        src = torch.randint(0, N, (300 if case == "hub" else 700,), generator=g)
         ei = torch.cat([torch.stack([src, torch.full_like(src, 40)]), torch.randint(0, N, (2, 1500), generator=g)], 1)
     elif case == "no_edges":
         N, ei = 70, torch.zeros(2, 0, dtype=torch.long)
@@ -53,7 +53,7 @@ def _fp64_autograd(c):
 
 
 @pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
-@pytest.mark.parametrize("case", ["random", "hub", "edge_dim2", "no_edges"])
+@pytest.mark.parametrize("case", ["random", "hub", "big_hub", "edge_dim2", "no_edges"])
 def test_generic_fused_nnconv_kernels_vs_fp64(cuda_device, H, case):
     from gnn_qot_estimation_amd import _lib
     from gnn_qot_estimation_amd import functional as QF
