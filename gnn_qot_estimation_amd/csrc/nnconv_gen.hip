@@ -132,6 +132,112 @@ __device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx,
     }
 }
 
+// gen_gather with the batch's per-edge values (source row, scale, h[K]) exchanged through LDS instead of DPP
+// broadcasts (r03).  Every lane of an 8-lane group still prefetches one in-edge of a batch of eight and evaluates
+// its h once; it then WRITES {j, scale, h[0..K)} as float4 chunks to the group's exchange slots and the group reads
+// edge u's chunks back as LDS broadcasts.  The DPP form costs 2 VALU moves per value and edge -- 20 values, 40 moves
+// against 36 (CPL = 4) or 72 (CPL = 8) FMAs -- and vector instructions of a gathering wave take issue cycles away
+// from the MFMA wave of the same SIMD one for one (section 4.4 of DESIGN.md), LDS reads do not.
+//   xch: float4 slots of THIS WAVE; chunk c of group gi, edge u at xch[(NCH * gi + c) * S + u]   (S = chunk stride)
+template <int D>
+struct XchW {
+    static constexpr int K = 2 * D;
+    static constexpr int NCH = (K + 2 + 3) / 4;     // float4 chunks per edge: {j, scale, h0, h1}, {h2..h5}, {h6, h7, -, -}
+};
+
+template <int D, int CPL, bool TRANSPOSE, int S>
+__device__ __forceinline__ void gen_gather_xch(const float* __restrict__ x, int ldx, int cbase, const float* __restrict__ ea,
+                                               const float* __restrict__ w1, const float* __restrict__ b1,
+                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                               const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, int64_t i,
+                                               int64_t N, float4* __restrict__ xch, float (&acc)[2 * D + 1][CPL],
+                                               float (&root)[CPL]) {
+    constexpr int K = 2 * D;
+    constexpr int NCH = XchW<D>::NCH;
+    const int sub = threadIdx.x & 7, gi = (threadIdx.x & 63) >> 3;
+#pragma unroll
+    for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[kk][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) root[c] = 0.f;
+    int beg = 0, end = 0;
+    float srow = 0.f;
+    if (i < N) {
+        beg = rowptr[i]; end = rowptr[i + 1];
+        if (!TRANSPOSE) srow = invdeg[i];
+        ldv<CPL>(x + i * ldx + cbase, root);
+    }
+    float4* mine = xch + NCH * gi * S;
+    for (int base = beg; base < end; base += 8) {
+        const int p = base + sub;
+        // dead slots of a batch (lane p >= end) carry h = 0 and scale = 0, so their terms vanish without per-use
+        // selects; their row load is pointed at the destination's own row (always a valid address)
+        float w[4 * NCH];
+#pragma unroll
+        for (int z = 0; z < 4 * NCH; ++z) w[z] = 0.f;
+        w[0] = __builtin_bit_cast(float, (int)i);
+        if (p < end) {
+            const int myj = col[p];
+            const int64_t e = eidx[p];
+            float ee[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
+            const float mysc = TRANSPOSE ? invdeg[myj] : 1.0f;
+            w[0] = __builtin_bit_cast(float, myj);
+            w[1] = mysc;
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                float h = b1[kk];
+#pragma unroll
+                for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
+                w[2 + kk] = fmaxf(h, 0.f) * mysc;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) mine[c * S + sub] = make_float4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+        const int cnt = (end - base < 8) ? end - base : 8;
+#define QOT_XCH_EDGE4(U0)                                                                                 \
+        {                                                                                                 \
+            float xv[4][CPL];                                                                             \
+            float4 q0[4];                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) q0[u] = mine[U0 + u];                           \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                 \
+                ldv<CPL>(x + (int64_t)__builtin_bit_cast(int, q0[u].x) * ldx + cbase, xv[u]);             \
+            float hh[4][4 * NCH];                                                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+                hh[u][0] = q0[u].x; hh[u][1] = q0[u].y; hh[u][2] = q0[u].z; hh[u][3] = q0[u].w;           \
+                _Pragma("unroll") for (int c = 1; c < NCH; ++c) {                                         \
+                    const float4 v = mine[c * S + U0 + u];                                                \
+                    hh[u][4 * c] = v.x; hh[u][4 * c + 1] = v.y; hh[u][4 * c + 2] = v.z; hh[u][4 * c + 3] = v.w; \
+                }                                                                                         \
+            }                                                                                             \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                               \
+                _Pragma("unroll") for (int kk = 0; kk < K; ++kk)                                          \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(hh[u][2 + kk], xv[u][c], acc[kk][c]); \
+                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(hh[u][1], xv[u][c], acc[K][c]); \
+            }                                                                                             \
+            /* four rows stay in flight, the vector work is skipped in pairs */                           \
+            if (cnt > U0 + 2) {                                                                           \
+                _Pragma("unroll") for (int u = 2; u < 4; ++u) {                                           \
+                    _Pragma("unroll") for (int kk = 0; kk < K; ++kk)                                      \
+                        _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(hh[u][2 + kk], xv[u][c], acc[kk][c]); \
+                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(hh[u][1], xv[u][c], acc[K][c]); \
+                }                                                                                         \
+            }                                                                                             \
+        }
+        QOT_XCH_EDGE4(0)
+        if (cnt > 4) QOT_XCH_EDGE4(4)
+#undef QOT_XCH_EDGE4
+    }
+    if (!TRANSPOSE) {
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) acc[kk][c] *= srow;
+    }
+}
+
 template <int H>
 struct GenW {
     static constexpr int CW = H < 64 ? H : 64;          // input channels per pass
@@ -189,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
     constexpr int CH = (GS % 4 == 0) ? 4 : ((GS % 2 == 0) ? 2 : 1);
     constexpr int NCH = GS / CH;
     constexpr int TILE_FLOATS = GMAIN * 8 * 32;
+    static_assert(2 * GMAIN >= 8 * XchW<D>::NCH, "exchange slots inside the tile");
     constexpr int RED_FLOATS = (KS > 1) ? 4 * 16 * 64 : 0;
     __shared__ __attribute__((aligned(16))) float At[TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS];
     const float4* At4 = reinterpret_cast<const float4*>(At);
@@ -225,8 +332,11 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
                     for (int c_ = 0; c_ < CPL; ++c_) root[c_] = 1.0f;
                 } else
 #endif
-                gen_gather<D, CPL, TRANSPOSE>(x, ldx, p * CW + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N,
-                                              0, 0x7fffffff, acc, root);
+                // (the exchange slots of the gather are float4 slots of the operand tile that only this wave's rows map
+                // to -- at4_slot keeps a wave's 8 rows inside its aligned 8 slots of every (group, half) line -- and the
+                // tile is free between the barrier that ended the last MFMA phase and this wave's own frag_store)
+                gen_gather_xch<D, CPL, TRANSPOSE, 32>(x, ldx, p * CW + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N,
+                                                      reinterpret_cast<float4*>(At) + 8 * wave, acc, root);
 #pragma unroll
                 for (int kk = 0; kk <= K; ++kk) frag_store<CW, CPL>(At, kk, sub, il, acc[kk]);
                 if (ROOT_LDS) frag_store<CW, CPL>(At, K + 1, sub, il, root);
@@ -391,12 +501,15 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
     constexpr int TPW = (NT + 3) / 4;               // per consumer wave (tile t belongs to consumer wave t % 4)
     __shared__ __attribute__((aligned(16))) float Atile[2][32 * ROWS];
     __shared__ __attribute__((aligned(16))) float Gt[2][32 * OC];
+    __shared__ float4 xchg[4][XchW<D>::NCH * 8 * 8];       // per producer wave: the gather's edge exchange slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave < 4;
     const int cw = wave & 3;                        // consumer wave index
     const int r31 = lane & 31, hi = lane >> 5;
     const int sub = threadIdx.x & 7, il = (threadIdx.x & 255) >> 3;
     const int slice = blockIdx.x % NSLICE, split = blockIdx.x / NSLICE;
+    // (r03, measured: all NSLICE slices of a node split on ONE XCD -- they read the same g rows and source rows -- took
+    // HBM fetch from 3.3x to 2.5x the algorithmic bytes at H = 128 but ran 4 % slower, 860 -> 894 us: not kept)
     const int a0 = (slice % NAC) * AC, o0 = (slice / NAC) * OC;
     const int64_t ntiles = (N + 31) / 32;
 
@@ -430,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
                 for (int c_ = 0; c_ < CPL; ++c_) root[c_] = 1.f;
             } else
 #endif
-            gen_gather<D, CPL, false>(x, ldx, a0 + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, 0, 0x7fffffff, acc, root);
+            gen_gather_xch<D, CPL, false, 8>(x, ldx, a0 + CPL * sub, ea, w1, b1, rowptr, col, eidx, invdeg, i, N, xchg[wave], acc, root);
 #pragma unroll
             for (int kk = 0; kk <= K; ++kk)
 #pragma unroll
@@ -492,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
         __syncthreads();
     }
     // slab[blockIdx][row (kk, a - a0)][o - o0]
-    float* slab = slabs + (int64_t)blockIdx.x * ROWS * OC;
+    float* slab = slabs + (int64_t)(split * NSLICE + slice) * ROWS * OC;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tt = cw + 4 * t;
