@@ -507,11 +507,29 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
     const int cw = wave & 3;                        // consumer wave index
     const int r31 = lane & 31, hi = lane >> 5;
     const int sub = threadIdx.x & 7, il = (threadIdx.x & 255) >> 3;
-    const int slice = blockIdx.x % NSLICE, split = blockIdx.x / NSLICE;
-    // (r03, measured: all NSLICE slices of a node split on ONE XCD -- they read the same g rows and source rows -- took
-    // HBM fetch from 3.3x to 2.5x the algorithmic bytes at H = 128 but ran 4 % slower, 860 -> 894 us: not kept)
-    const int a0 = (slice % NAC) * AC, o0 = (slice / NAC) * OC;
     const int64_t ntiles = (N + 31) / 32;
+    // Walk of the node tiles.  Plain: slice = blockIdx % NSLICE, tiles split, split + nsplit, ...  XCD-aware (workgroups
+    // are dealt round-robin over the 8 XCDs, blockIdx % 8, each with a private L2): an XCD owns a contiguous eighth of the
+    // tiles, all NSLICE slices of a split sit on that XCD, and its nsplit / 8 splits walk neighbouring tiles at the same
+    // time -- the g rows one slice fetches the other slices find in that L2, and so do neighbouring tiles (the same
+    // graph) the source rows they share.  Measured (r03, N = 256 000): HBM fetch 954 -> 289 MB at H = 128 (3.5x -> 1.15x
+    // the algorithmic bytes) for 863 -> 877 us; at H = 256 (16 slices) 3367 -> 3506 us, so only widths with <= 4 slices
+    // take it.  (Every split a contiguous run of tiles, or the slices' starts rotated: slower, tools/experiments.)
+    int slice = blockIdx.x % NSLICE, split = blockIdx.x / NSLICE;
+    int64_t t_first = split, t_step = nsplit, t_end = ntiles;
+    if (nsplit % 8 == 0 && NSLICE <= 4) {
+        const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+        const int sl = q / NSLICE;
+        slice = q % NSLICE;
+        split = sl * 8 + xcd;
+        const int64_t chunk = (ntiles + 7) / 8;
+        t_first = xcd * chunk + sl;
+        t_step = nsplit / 8;
+        t_end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+    }
+    const int n_mine = t_first < t_end ? (int)((t_end - t_first + t_step - 1) / t_step) : 0;
+    auto tile_of = [&](int k) -> int64_t { return t_first + (int64_t)k * t_step; };
+    const int a0 = (slice % NAC) * AC, o0 = (slice / NAC) * OC;
 
     // The two roles are two separate loops with the same barrier count, so that the consumers' 80 accumulator registers
     // are not live in the producers' code (one loop with a role branch inside spilled 192 B/lane at 128 registers).
@@ -551,13 +569,12 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
 #pragma unroll
             for (int c_ = 0; c_ < CPL; ++c_) Atile[buf][il * ROWS + (K + 1) * AC + CPL * sub + c_] = root[c_];
         };
-        int64_t tile = split;
-        if (tile < ntiles) fill(tile, 0);
+        if (n_mine > 0) fill(tile_of(0), 0);
         __syncthreads();
         int buf = 0;
 #pragma unroll 1
-        for (; tile < ntiles; tile += nsplit, buf ^= 1) {
-            if (tile + nsplit < ntiles) fill(tile + nsplit, buf ^ 1);
+        for (int k = 0; k < n_mine; ++k, buf ^= 1) {
+            if (k + 1 < n_mine) fill(tile_of(k + 1), buf ^ 1);
             __syncthreads();
         }
         return;
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void nnconv_dw_gen_kernel(
     __syncthreads();
     int buf = 0;
 #pragma unroll 1
-    for (int64_t tile = split; tile < ntiles; tile += nsplit, buf ^= 1) {
+    for (int k = 0; k < n_mine; ++k, buf ^= 1) {
 #ifdef QOT_DIAG
         if (variant != 3)
 #endif

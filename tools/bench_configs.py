@@ -54,6 +54,13 @@ def lp_loss(m, b):
 
 
 which = sys.argv[1:] or ["cfg1", "ref_topo", "ref_lp", "cfg3", "cfg4", "cfg5"]
+if len(which) > 1:
+    # one fresh process per config (this one has not touched the GPU): behind cfg3's 11 GB of freed blocks in the same
+    # process cfg4 measured 31.2 ms against 28.8 ms on its own -- the allocator's history, not the kernels
+    import subprocess
+    for name in which:
+        subprocess.run([sys.executable, os.path.abspath(__file__), name], check=True)
+    sys.exit(0)
 torch.manual_seed(0)
 if "cfg1" in which:   # plumbing config (runs on GPU here; the reference runs it on CPU)
     run("cfg1: NSFNET 14n, H=32, B=16", q.TopologicalGNN(14, 32, 3, 4), S.topological_batch(1, 16).to(dev), topo_loss)
