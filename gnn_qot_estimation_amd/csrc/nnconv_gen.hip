@@ -15,9 +15,11 @@
 //                          gathers only its 16 channels of the operand.  Slabs are summed in a fixed order by
 //                          nnconv_dw_final_kernel straight into the parameters' own layouts.
 //   nnconv_gradh_gen_kernel  grad of the edge MLP's first layer: per tile GA = g_tile @ Wk^T for 32 input channels at
-//                          a time on the matrix cores, per-edge dots against the source rows; with more than one
-//                          channel pass the per-edge partial dots wait in LDS (edges of a tile are one CSR range).
-// All sums have a fixed order: bitwise reproducible, independent of where a graph sits in the batch.
+//                          a time on the matrix cores, per-edge dots against the source rows.  The tile's edges are
+//                          staged in LDS once and dealt evenly over the lane groups (the results are sums over all
+//                          lanes), every pass adds its share straight into those sums (the gradient is linear in the dots).
+// All sums have a fixed order: bitwise reproducible; per-node results (forward, adjoint) do not depend on where a graph
+// sits in the batch.
 #include "common.hpp"
 #include "mfma_tile.hpp"
 
