@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 6          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 7          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -113,6 +113,8 @@ SIGNATURES = {
     "qot_gemm_tn_splits": (_int, [_int, _int, _i64]),
     "qot_gemm_tn_planes": (_int, [_p, _i64, _p, _i64, _p, _int, _int, _i64, _int, _p, _p, _p]),
     "qot_skinny_linear_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "qot_skinny_linear_fwd_logits": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p]),
+    "qot_gemm_nt_logits": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "qot_skinny_linear_dw_blocks": (_int, [_i64]),
     "qot_skinny_linear_dw": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_run_roles": (_int, [_p, _int, _p]),

@@ -106,11 +106,18 @@ __device__ __forceinline__ void gemm_tile_to_lds(float* __restrict__ tile, const
 // ---- NT: both operands row-major [rows, K] ---------------------------------------------------------------------
 // thread t owns (row, group) pairs pi = t, t + 256 of each operand: row = pi / 4, g = pi % 4 -> 8 consecutive k (32 B);
 // four neighbouring lanes read one 128-B row segment
-template <bool AFFINE>
+// LOGITS (r03): the 128 columns of an output tile are ONE attention head of GATConv (C = 128 channels per head), so the
+// head's two attention logits of the tile's rows, a_src[m, h] = <out[m, h, :], att_src[h, :]> and a_dst likewise
+// (lightpath_training/models.py:13 -> PyG GATConv's alpha_src / alpha_dst), are complete inside the tile: they are formed
+// from the LDS image of the epilogue and the separate pass over the [M, 4C] matrix (gat_logits_kernel) is not needed.
+template <bool AFFINE, bool LOGITS = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                          int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                          int K, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float* __restrict__ bias) {
+                                                         const float* __restrict__ shift, const float* __restrict__ bias,
+                                                         const float* __restrict__ att_src = nullptr,
+                                                         const float* __restrict__ att_dst = nullptr,
+                                                         float* __restrict__ a_src = nullptr, float* __restrict__ a_dst = nullptr) {
     __shared__ __attribute__((aligned(16))) float4 lds[2][2][1024];       // [stage][operand][slot]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
@@ -206,6 +213,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
             float4 v = ld4(tile + pm * 128 + ((4 * q4) ^ ((pm & 7) << 2)));
             if (bias) { const float4 bz = ld4(bias + col); v = add4(v, bz); }
             st4(C + row * ldc + col, v);
+        }
+    }
+    if (LOGITS) {
+        // thread t: tile row t / 2, columns 64 (t & 1) .. + 64; the two halves of a row meet in neighbouring lanes
+        const int pm = t >> 1, half = t & 1;
+        const int64_t row = m0 + pm;
+        float ps = 0.f, pd = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int cq = 64 * half + 4 * q;
+            float4 v = ld4(tile + pm * 128 + (cq ^ ((pm & 7) << 2)));
+            if (bias) v = add4(v, ld4(bias + n0 + cq));
+            ps += dot4(v, ld4(att_src + n0 + cq));
+            pd += dot4(v, ld4(att_dst + n0 + cq));
+        }
+        ps += dpp_move<0xB1>(ps);              // quad_perm [1,0,3,2]: lane ^ 1
+        pd += dpp_move<0xB1>(pd);
+        if (half == 0 && row < M) {
+            const int heads = N / kGemmBN;
+            a_src[row * heads + ct] = ps;
+            a_dst[row * heads + ct] = pd;
         }
     }
 }
@@ -336,6 +364,30 @@ extern "C" int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t 
         gemm_nt_kernel<true><<<(int)tiles, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias);
     else
         gemm_nt_kernel<false><<<(int)tiles, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, bias);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// qot_gemm_nt with GATConv's attention logits from the epilogue: N = heads * 128 (one output tile per head), att_src /
+// att_dst [heads * 128], a_src / a_dst [M, heads] (see gemm_nt_kernel<., LOGITS>)
+extern "C" int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                                  int N, int K, const float* scale, const float* shift, const float* bias,
+                                  const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                                  qot_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return QOT_ERR_BADARG;
+    if (M == 0) return QOT_OK;
+    if (!A || !B || !C || (scale && !shift) || !att_src || !att_dst || !a_src || !a_dst) return QOT_ERR_BADARG;
+    if ((K % kGemmBK) || (N % kGemmBN) || (lda & 3) || (ldb & 3) || (ldc & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+        ((uintptr_t)C & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)att_src & 15) || ((uintptr_t)att_dst & 15))
+        return QOT_ERR_UNSUPPORTED;
+    const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * (N / kGemmBN);
+    if (tiles > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+    if (scale)
+        gemm_nt_kernel<true, true><<<(int)tiles, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias,
+                                                                              att_src, att_dst, a_src, a_dst);
+    else
+        gemm_nt_kernel<false, true><<<(int)tiles, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr,
+                                                                               bias, att_src, att_dst, a_src, a_dst);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

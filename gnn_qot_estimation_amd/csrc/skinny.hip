@@ -8,9 +8,14 @@ namespace qot {
 
 constexpr int kSkinnyMaxF = 8;
 
-// out[n, c] = sum_f x[n, f] w[c, f] (+ 0): thread = (float4 column group, row slot); rows walked grid-stride
+// out[n, c] = sum_f x[n, f] w[c, f] (+ 0): thread = (float4 column group, row slot); rows walked grid-stride.
+// LOGITS: C = heads * 128; the 32 lanes that hold a head's 128 columns of a row also form GATConv's attention logits
+// a_src[n, h] = <out[n, h, :], att_src[h, :]>, a_dst likewise (as gemm_nt_kernel<., LOGITS>).
+template <bool LOGITS>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ out, int64_t N, int F, int C) {
+                                                         float* __restrict__ out, int64_t N, int F, int C,
+                                                         const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                         float* __restrict__ a_src, float* __restrict__ a_dst) {
     const int C4 = C / 4;
     const int cg = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
     float wr[4][kSkinnyMaxF];
@@ -19,6 +24,8 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int f = 0; f < kSkinnyMaxF; ++f) wr[c][f] = (f < F) ? w[(int64_t)(4 * cg + c) * F + f] : 0.f;
     if (slot >= nslot) return;
+    float4 as4 = f4zero(), ad4 = f4zero();
+    if (LOGITS) { as4 = ld4(att_src + 4 * cg); ad4 = ld4(att_dst + 4 * cg); }
     for (int64_t n = (int64_t)blockIdx.x * nslot + slot; n < N; n += (int64_t)gridDim.x * nslot) {
         float xv[kSkinnyMaxF];
 #pragma unroll
@@ -29,6 +36,11 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = fmaf(xv[f], wr[c][f], o[c]);
         st4(out + n * C + 4 * cg, make_float4(o[0], o[1], o[2], o[3]));
+        if (LOGITS) {                                  // (C4 a multiple of 32: a head's lanes are an aligned half wave)
+            const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            const float ps = group_sum<32>(dot4(ov, as4)), pd = group_sum<32>(dot4(ov, ad4));
+            if ((cg & 31) == 0) { a_src[n * (C4 / 32) + cg / 32] = ps; a_dst[n * (C4 / 32) + cg / 32] = pd; }
+        }
     }
 }
 
@@ -84,7 +96,25 @@ extern "C" int qot_skinny_linear_fwd(const float* x, const float* w, float* out,
     const int nslot = 256 / (C / 4);
     int64_t blocks = (N + nslot - 1) / nslot;
     if (blocks > 8192) blocks = 8192;
-    skinny_fwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, w, out, N, F, C);
+    skinny_fwd_kernel<false><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, w, out, N, F, C, nullptr, nullptr, nullptr, nullptr);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// ... with GATConv's attention logits: C = heads * 128 (heads = 1 or 2 per 256-thread row slot: C in {128, 256, 512, 1024}),
+// att_src / att_dst [C], a_src / a_dst [N, C / 128]
+extern "C" int qot_skinny_linear_fwd_logits(const float* x, const float* w, float* out, int64_t N, int F, int C,
+                                            const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                                            qot_stream_t stream) {
+    if (N < 0 || F <= 0 || C <= 0) return QOT_ERR_BADARG;
+    if (F > kSkinnyMaxF || (C % 128) || C > 1024 || (256 % (C / 4))) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!x || !w || !out || !att_src || !att_dst || !a_src || !a_dst) return QOT_ERR_BADARG;
+    if (((uintptr_t)att_src & 15) || ((uintptr_t)att_dst & 15)) return QOT_ERR_UNSUPPORTED;
+    const int nslot = 256 / (C / 4);
+    int64_t blocks = (N + nslot - 1) / nslot;
+    if (blocks > 8192) blocks = 8192;
+    skinny_fwd_kernel<true><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, w, out, N, F, C, att_src, att_dst, a_src, a_dst);
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

@@ -882,16 +882,22 @@ class GatFn(torch.autograd.Function):
     (``BnFn`` ``partials=``): one pass over ``[N, 4C]`` fewer per layer."""
 
     @staticmethod
-    def forward(ctx, z, att_src, att_dst, bias, graph: GraphIndex, neg_slope: float, bn_stats: bool = False):
+    def forward(ctx, z, att_src, att_dst, bias, graph: GraphIndex, neg_slope: float, bn_stats: bool = False,
+                a_src=None, a_dst=None):
+        """``a_src`` / ``a_dst``: the logits, when the projection that made ``z`` left them behind (``gemm_nt(att=...)``);
+        their gradient still returns through ``grad_z`` in ``backward``."""
         require_cuda(z, att_src, att_dst, bias)
         z, bias = _f32c(z), _f32c(bias)
         heads, C = att_src.shape[-2], att_src.shape[-1]
         att_s, att_d = _f32c(att_src).reshape(-1), _f32c(att_dst).reshape(-1)
         N, HC = z.shape
         dev = z.device
-        a_src = torch.empty(N, heads, dtype=torch.float32, device=dev)
-        a_dst = torch.empty(N, heads, dtype=torch.float32, device=dev)
-        _lib.call("qot_gat_logits", P(z), P(att_s), P(att_d), P(a_src), P(a_dst), N, heads, C)
+        if a_src is None or a_dst is None:
+            a_src = torch.empty(N, heads, dtype=torch.float32, device=dev)
+            a_dst = torch.empty(N, heads, dtype=torch.float32, device=dev)
+            _lib.call("qot_gat_logits", P(z), P(att_s), P(att_d), P(a_src), P(a_dst), N, heads, C)
+        else:
+            a_src, a_dst = _f32c(a_src), _f32c(a_dst)
         out = torch.empty(N, HC, dtype=torch.float32, device=dev)
         stats = torch.empty(N, heads, 2, dtype=torch.float32, device=dev)
         partials = None
@@ -930,7 +936,7 @@ class GatFn(torch.autograd.Function):
         g_att = torch.empty(2, HC, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
         _lib.call("qot_gat_att_grad", P(z), P(gas), P(gad), _off(g_att, 0), _off(g_att, HC), P(ws), N, heads, C)
-        return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), colsum(g), None, None, None
+        return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), colsum(g), None, None, None, None, None
 
 
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)
@@ -1055,14 +1061,27 @@ def _bn_backward(g, x, bias, mean, rstd, weight, n_tot, training, relu, synced):
     return gx, gw, gb
 
 
-def gemm_nt(a, b, scale=None, shift=None, bias=None):
+def gemm_nt(a, b, scale=None, shift=None, bias=None, att=None):
     """``a' @ b.T (+ bias)`` on ``qot_gemm_nt`` (``a'`` = ``relu(a * scale + shift)`` when given); ``a [M, K]``, ``b [N, K]``
-    contiguous fp32, K a multiple of 32."""
+    contiguous fp32, K a multiple of 32.  ``att = (att_src, att_dst)`` (flat ``[N]``, N = heads * 128): also returns
+    GATConv's attention logits ``(a_src, a_dst)`` ``[M, heads]`` from the epilogue (``qot_gemm_nt_logits``)."""
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    _lib.call("qot_gemm_nt", P(a), K, P(b), K, P(out), N, M, N, K, P(scale), P(shift), P(bias))
-    return out
+    if att is None:
+        _lib.call("qot_gemm_nt", P(a), K, P(b), K, P(out), N, M, N, K, P(scale), P(shift), P(bias))
+        return out
+    heads = N // 128
+    a_src = torch.empty(M, heads, dtype=torch.float32, device=a.device)
+    a_dst = torch.empty(M, heads, dtype=torch.float32, device=a.device)
+    _lib.call("qot_gemm_nt_logits", P(a), K, P(b), K, P(out), N, M, N, K, P(scale), P(shift), P(bias), P(att[0]), P(att[1]),
+              P(a_src), P(a_dst))
+    return out, a_src, a_dst
+
+
+def logits_ok(out_features: int, heads: int) -> bool:
+    """The projection's epilogue can form GATConv's attention logits: one 128-column output tile per head."""
+    return heads >= 1 and out_features == heads * 128 and os.environ.get("QOT_NO_FUSED_LOGITS", "0") != "1"
 
 
 def gemm_tn_planes(a_t, b_t, scale=None, shift=None):
@@ -1092,19 +1111,28 @@ class SkinnyLinearFn(torch.autograd.Function):
     gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, att_src=None, att_dst=None):
+        """``att_src`` / ``att_dst`` (GATConv's, ``[1, heads, 128]``): also returns the attention logits ``(a_src, a_dst)``
+        (non-differentiable here: ``GatFn.backward`` sends their gradient into ``grad_z``)."""
         require_cuda(x, weight)
         x, weight = _f32c(x), _f32c(weight)
         N, F = x.shape
         C = weight.shape[0]
         out = torch.empty(N, C, dtype=torch.float32, device=x.device)
-        _lib.call("qot_skinny_linear_fwd", P(x), P(weight), P(out), N, F, C)
         ctx.save_for_backward(x)
         ctx.dims = (N, F, C)
-        return out
+        if att_src is None:
+            _lib.call("qot_skinny_linear_fwd", P(x), P(weight), P(out), N, F, C)
+            return out
+        a_src = torch.empty(N, C // 128, dtype=torch.float32, device=x.device)
+        a_dst = torch.empty(N, C // 128, dtype=torch.float32, device=x.device)
+        _lib.call("qot_skinny_linear_fwd_logits", P(x), P(weight), P(out), N, F, C, P(_f32c(att_src.detach()).reshape(-1)),
+                  P(_f32c(att_dst.detach()).reshape(-1)), P(a_src), P(a_dst))
+        ctx.mark_non_differentiable(a_src, a_dst)
+        return out, a_src, a_dst
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_unused):
         (x,) = ctx.saved_tensors
         N, F, C = ctx.dims
         g = _f32c(g)
@@ -1113,7 +1141,7 @@ class SkinnyLinearFn(torch.autograd.Function):
         _lib.call("qot_skinny_linear_dw", P(g), P(x), P(part), N, F, C)
         gw = torch.empty(C * F, dtype=torch.float32, device=g.device)
         _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, gw), (nblk, C * F, 0))])
-        return None, gw.view(C, F)
+        return None, gw.view(C, F), None, None
 
 
 def skinny_ok(f: int, c: int) -> bool:
@@ -1148,32 +1176,43 @@ class BnLinearFn(torch.autograd.Function):
     from ``x`` as ``BnFn`` does.  Statistics, running-statistics update and distributed behaviour are ``BnFn``'s."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, sync, partials, lin_weight):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, sync, partials, lin_weight,
+                att_src=None, att_dst=None):
+        """``att_src`` / ``att_dst`` (the next GATConv's, 128 channels per head): also returns that layer's attention logits
+        ``(a_src, a_dst)`` from the product's epilogue (non-differentiable here, see ``SkinnyLinearFn``)."""
         require_cuda(x, weight, bias, lin_weight)
         x, weight, bias, lin_weight = _f32c(x), _f32c(weight), _f32c(bias), _f32c(lin_weight)
         N, C = x.shape
         mean, rstd, n_tot, world = _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, partials)
         scale = (rstd * weight).contiguous()                 # y = relu(x * scale + shift)
         shift = torch.addcmul(bias, mean, scale, value=-1.0).contiguous()
-        z = gemm_nt(x, lin_weight, scale, shift) if N > 0 else x.new_empty(0, lin_weight.shape[0])
         ctx.save_for_backward(x, bias, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0), lin_weight,
                               scale, shift)
         ctx.cfg = (bool(training), world > 1)
+        if att_src is not None and N > 0:
+            z, a_src, a_dst = gemm_nt(x, lin_weight, scale, shift,
+                                      att=(_f32c(att_src.detach()).reshape(-1), _f32c(att_dst.detach()).reshape(-1)))
+            ctx.mark_non_differentiable(a_src, a_dst)
+            return z, a_src, a_dst
+        z = gemm_nt(x, lin_weight, scale, shift) if N > 0 else x.new_empty(0, lin_weight.shape[0])
+        if att_src is not None:
+            e = x.new_empty(0, lin_weight.shape[0] // 128)
+            return z, e, e.clone()
         return z
 
     @staticmethod
-    def backward(ctx, gz):
+    def backward(ctx, gz, *_unused):
         x, bias, mean, rstd, weight, n_tot, lin_weight, scale, shift = ctx.saved_tensors
         training, synced = ctx.cfg
         gz = _f32c(gz)
         N, C = x.shape
         if N == 0:
             return (torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(bias), None, None, None, None, None,
-                    None, None, torch.zeros_like(lin_weight))
+                    None, None, torch.zeros_like(lin_weight), None, None)
         gy = gz @ lin_weight                                 # [N, C]: the library's product (135 vs 122 TFLOP/s, DESIGN 4.7)
         g_lin = gemm_tn_planes(gz, x, scale, shift)          # [out, C] = gz^T relu(bn(x))
         gx, gw, gb = _bn_backward(gy, x, bias, mean, rstd, weight, n_tot, training, True, synced)
-        return gx, gw, gb, None, None, None, None, None, None, None, g_lin
+        return gx, gw, gb, None, None, None, None, None, None, None, g_lin, None, None
 
 
 # ------------------------------------------------------------------ LUT rows (a9)

@@ -98,17 +98,21 @@ class LightpathGNN(nn.Module):
         pending = None             # (norm, raw conv output, BatchNorm partials) whose BatchNorm + ReLU the next projection applies
         for layer in range(1, self.num_layers + 1):
             conv, norm = getattr(self, f"conv{layer}"), getattr(self, f"norm{layer}")
+            # (the projection's epilogue also leaves the layer's attention logits where a head is 128 channels wide)
             if pending is None:
-                z = conv.project(x)
+                z, logits = conv.project(x, with_logits=True)
             else:                  # relu(norm(x)) @ W^T with the normalised activations never written to memory
                 pnorm, praw, ppart = pending
-                z = pnorm.project_relu(praw, conv.lin.weight, partials=ppart)
+                if QF.logits_ok(conv.lin.out_features, conv.heads):
+                    z, logits = pnorm.project_relu(praw, conv.lin.weight, partials=ppart, att=(conv.att_src, conv.att_dst))
+                else:
+                    z, logits = pnorm.project_relu(praw, conv.lin.weight, partials=ppart), None
                 pending = None
             if self.training:      # the conv's epilogue leaves the BatchNorm's column partials behind
-                raw, part = conv.attend(z, graph, bn_stats=True)
+                raw, part = conv.attend(z, graph, bn_stats=True, logits=logits)
                 partials = (part, conv.bias)
             else:
-                raw, partials = conv.attend(z, graph), None
+                raw, partials = conv.attend(z, graph, logits=logits), None
             width = raw.shape[1]
             # BatchNorm + ReLU folded into the NEXT projection's operand load (QF.BnLinearFn): the normalised activations are
             # never written to / read from HBM (one [N, 4C] tensor less resident per layer); the product runs on

@@ -159,20 +159,33 @@ class GATConv(nn.Module):
             raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
         return self.attend(self.project(x), graph, bn_stats)
 
-    def project(self, x):
+    def project(self, x, with_logits: bool = False):
         """``z = x W^T`` (``lin``, no bias): own MFMA kernel where the inner width allows (``csrc/gemm.hip``), the library
-        for the first layer's handful of input features."""
+        for the first layer's handful of input features.  ``with_logits``: returns ``(z, logits)`` where ``logits`` is
+        ``(a_src, a_dst)`` when the kernel formed them in its epilogue (128 channels per head), else ``None``."""
+        logits = None
         if x.is_cuda and x.dtype == torch.float32 and x.shape[0] > 0:
             if QF.gemm_ok(x.shape[1], self.lin.out_features):
-                return QF.GemmFn.apply(x, self.lin.weight)
-            if QF.skinny_ok(x.shape[1], self.lin.out_features) and not x.requires_grad:
-                return QF.SkinnyLinearFn.apply(x, self.lin.weight)     # first layer: F = 5 raw node features
-        return self.lin(x)
+                z = QF.GemmFn.apply(x, self.lin.weight)
+            elif QF.skinny_ok(x.shape[1], self.lin.out_features) and not x.requires_grad:
+                # first layer: F = 5 raw node features
+                if with_logits and QF.logits_ok(self.lin.out_features, self.heads) and self.lin.out_features in (128, 256, 512, 1024):
+                    z, a_s, a_d = QF.SkinnyLinearFn.apply(x, self.lin.weight, self.att_src, self.att_dst)
+                    logits = (a_s, a_d)
+                else:
+                    z = QF.SkinnyLinearFn.apply(x, self.lin.weight)
+            else:
+                z = self.lin(x)
+        else:
+            z = self.lin(x)
+        return (z, logits) if with_logits else z
 
-    def attend(self, z, graph: GraphIndex, bn_stats: bool = False):
+    def attend(self, z, graph: GraphIndex, bn_stats: bool = False, logits=None):
         # attention logits a[n,h] = <z[n,h,:], att[h,:]> are formed from z inside the operator (one pass over z each
-        # way); their gradient returns into grad_z in the source pass of the backward
-        return QF.GatFn.apply(z, self.att_src, self.att_dst, self.bias, graph, self.negative_slope, bn_stats)
+        # way) unless the projection left them behind (``logits``); their gradient returns into grad_z in the source pass
+        # of the backward either way
+        a_s, a_d = logits if logits is not None else (None, None)
+        return QF.GatFn.apply(z, self.att_src, self.att_dst, self.bias, graph, self.negative_slope, bn_stats, a_s, a_d)
 
 
 class BatchNorm(nn.Module):
@@ -197,16 +210,21 @@ class BatchNorm(nn.Module):
         return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
                              m.momentum, m.eps, relu, self.sync_stats, partials)
 
-    def project_relu(self, x, lin_weight, partials=None):
+    def project_relu(self, x, lin_weight, partials=None, att=None):
         """``relu(self(x)) @ lin_weight^T`` without materialising the normalised activations (``QF.BnLinearFn``): this
-        layer's BatchNorm + ReLU ride in the operand load of the next layer's projection."""
+        layer's BatchNorm + ReLU ride in the operand load of the next layer's projection.  ``att = (att_src, att_dst)`` of
+        that next GATConv: returns ``(z, (a_src, a_dst))`` with its attention logits from the product's epilogue."""
         m = self.module
         if self.training:
             m.num_batches_tracked.add_(1)
         if partials is not None and not (self.training and QF._dist_world()[1] == 1):
             partials = None
-        return QF.BnLinearFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum, m.eps,
-                                   self.sync_stats, partials, lin_weight)
+        if att is None:
+            return QF.BnLinearFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum, m.eps,
+                                       self.sync_stats, partials, lin_weight)
+        z, a_s, a_d = QF.BnLinearFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum,
+                                          m.eps, self.sync_stats, partials, lin_weight, att[0], att[1])
+        return z, (a_s, a_d)
 
 
 def global_mean_pool(x, batch, size: Optional[int] = None, data=None):

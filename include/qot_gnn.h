@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 6
+#define QOT_ABI_VERSION 7
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -457,6 +457,13 @@ int qot_gather3(const float* s0, int64_t n0, const float* s1, int64_t n1, const 
  * order (QOT_ROLE_SUM_ROWS: bitwise reproducible).  M, N multiples of 4; splits = qot_gemm_tn_splits(M, N, K). */
 int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                 const float* scale, const float* shift, const float* bias, qot_stream_t stream);
+/* qot_gemm_nt_logits: qot_gemm_nt for GATConv with 128 channels per head (N = heads * 128: one 128-column output tile per
+ * head), which also leaves the attention logits a_src[m, h] = <C[m, h, :], att_src[h, :]>, a_dst likewise ([M, heads];
+ * PyG GATConv's alpha_src / alpha_dst, lightpath_training/models.py:13) -- formed in the epilogue instead of by another
+ * pass over the [M, 4C] matrix (qot_gat_logits).  att_src / att_dst: [N] floats, 16-byte aligned. */
+int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                       const float* scale, const float* shift, const float* bias, const float* att_src,
+                       const float* att_dst, float* a_src, float* a_dst, qot_stream_t stream);
 int qot_gemm_tn_splits(int M, int N, int64_t K);
 int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int M, int N, int64_t K,
                        int splits, const float* scale, const float* shift, qot_stream_t stream);
@@ -465,6 +472,9 @@ int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, int64_t ldb,
  * ...).lin): out[N, C] = x[N, F] . w[C, F]^T, F <= 8, C multiple of 4 (<= 1024) -- pure bandwidth; and its weight gradient
  * g^T x as per-workgroup partials [qot_skinny_linear_dw_blocks(N)][C * F] the caller sums in order (QOT_ROLE_SUM_ROWS). */
 int qot_skinny_linear_fwd(const float* x, const float* w, float* out, int64_t N, int F, int C, qot_stream_t stream);
+/* ... with the attention logits of qot_gemm_nt_logits (C = heads * 128, C in {128, 256, 512, 1024}) */
+int qot_skinny_linear_fwd_logits(const float* x, const float* w, float* out, int64_t N, int F, int C, const float* att_src,
+                                 const float* att_dst, float* a_src, float* a_dst, qot_stream_t stream);
 int qot_skinny_linear_dw_blocks(int64_t N);
 int qot_skinny_linear_dw(const float* g, const float* x, float* partials, int64_t N, int F, int C, qot_stream_t stream);
 

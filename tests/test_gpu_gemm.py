@@ -113,3 +113,45 @@ def test_skinny_first_layer_projection_and_weight_gradient(cuda_device, N, F, C)
     w.grad = None
     QF.SkinnyLinearFn.apply(x, w).backward(g)
     assert torch.equal(g1, w.grad)
+
+
+@pytest.mark.parametrize("M,heads,K", [(1000, 4, 512), (77, 1, 64), (4099, 2, 128)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_gemm_nt_logits_epilogue_matches_fp64(cuda_device, M, heads, K, affine):
+    """qot_gemm_nt_logits: the product and GATConv's attention logits a[m, h] = <out[m, h, :], att[h, :]> (128 channels per
+    head, PyG GATConv alpha_src / alpha_dst) from the same launch."""
+    from gnn_qot_estimation_amd import _lib
+    torch.manual_seed(2)
+    dev = cuda_device
+    N = heads * 128
+    A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5
+    scale, shift = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)) if affine else (None, None)
+    att_s, att_d = torch.randn(N, device=dev), torch.randn(N, device=dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    a_s, a_d = torch.full((M, heads), float("nan"), device=dev), torch.full((M, heads), float("nan"), device=dev)
+    _lib.call("qot_gemm_nt_logits", A, K, B, K, C, N, M, N, K, scale, shift, None, att_s, att_d, a_s, a_d)
+    Ad = torch.relu(A.double() * scale.double() + shift.double()) if affine else A.double()
+    ref = Ad @ B.double().t()
+    assert _rel(C, ref) <= 1e-5
+    assert _rel(a_s, (ref.view(M, heads, 128) * att_s.double().view(heads, 128)).sum(-1)) <= 1e-5
+    assert _rel(a_d, (ref.view(M, heads, 128) * att_d.double().view(heads, 128)).sum(-1)) <= 1e-5
+    # a width that is not one tile per head is refused, not mis-computed
+    with pytest.raises(_lib.QotError):
+        _lib.call("qot_gemm_nt_logits", A, K, B, K, C, N - 64, M, N - 64, K, scale, shift, None, att_s, att_d, a_s, a_d)
+
+
+@pytest.mark.parametrize("N,F,C", [(1001, 5, 512), (64, 8, 128), (300, 3, 256)])
+def test_skinny_projection_logits_match_fp64(cuda_device, N, F, C):
+    from gnn_qot_estimation_amd import _lib
+    torch.manual_seed(3)
+    dev = cuda_device
+    heads = C // 128
+    x, w = torch.randn(N, F, device=dev), torch.randn(C, F, device=dev)
+    att_s, att_d = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    out = torch.full((N, C), float("nan"), device=dev)
+    a_s, a_d = torch.full((N, heads), float("nan"), device=dev), torch.full((N, heads), float("nan"), device=dev)
+    _lib.call("qot_skinny_linear_fwd_logits", x, w, out, N, F, C, att_s, att_d, a_s, a_d)
+    ref = x.double() @ w.double().t()
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(a_s, (ref.view(N, heads, 128) * att_s.double().view(heads, 128)).sum(-1)) <= 1e-5
+    assert _rel(a_d, (ref.view(N, heads, 128) * att_d.double().view(heads, 128)).sum(-1)) <= 1e-5
