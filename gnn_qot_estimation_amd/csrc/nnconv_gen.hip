@@ -441,11 +441,48 @@ __global__ __launch_bounds__(256, 2) void nnconv_gen_kernel(
             for (int q = 0; q < CBW; ++q) {
                 const int colg = (cb0 + q) * 32 + r31;
                 const float bz = bias ? bias[colg] : 0.f;
+                if (act.enabled && act.thr16) {
+                    // Dropout draws: one 64-bit hash serves the four columns of a float4 group, i.e. the four lanes of a quad
+                    // for the same row.  Lane j of a quad hashes rows j, j + 4, j + 8, j + 12 of the accumulator and the quad
+                    // shares them through quad_perm broadcasts: 4 hashes + 32 DPP moves per lane and column block instead of
+                    // 16 hashes (as the H = 64 kernel; the draws are those of qot_act_fwd / act_apply1).
+                    const uint64_t dstep = (uint64_t)act.step[0];
+                    const int jq = r31 & 3;
+                    uint32_t mylo[4], myhi[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const int64_t io = tile0 + row;
-                    if (io < N) out[io * H + colg] = act_apply1(c[q][r] + bz, act, (uint64_t)(io * H + colg));
+                    for (int t = 0; t < 4; ++t) {
+                        const int rr = jq + 4 * t;
+                        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+                        const uint64_t flat = (uint64_t)((tile0 + row) * H + colg);
+                        const uint64_t z = act_hash64(act.seed, dstep, flat >> 2);
+                        mylo[t] = (uint32_t)z; myhi[t] = (uint32_t)(z >> 32);
+                    }
+                    uint32_t zlo[16], zhi[16];
+#define QOT_GEN_ZSHARE(S)                                                                                \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
+                        zlo[(S) + 4 * t] = __builtin_amdgcn_update_dpp(0, mylo[t], (S) * 0x55, 0xF, 0xF, true); \
+                        zhi[(S) + 4 * t] = __builtin_amdgcn_update_dpp(0, myhi[t], (S) * 0x55, 0xF, 0xF, true); \
+                    }
+                    QOT_GEN_ZSHARE(0) QOT_GEN_ZSHARE(1) QOT_GEN_ZSHARE(2) QOT_GEN_ZSHARE(3)
+#undef QOT_GEN_ZSHARE
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int64_t io = tile0 + row;
+                        const float v = c[q][r] + bz;
+                        float y = v > 0.f ? v : act.slope * v;
+                        const uint32_t half = (jq & 2) ? zhi[r] : zlo[r];
+                        const bool keep = ((half >> (16 * (jq & 1))) & 0xFFFFu) >= act.thr16;
+                        y = keep ? y * act.keep_scale : 0.f;
+                        if (io < N) out[io * H + colg] = y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int64_t io = tile0 + row;
+                        if (io < N) out[io * H + colg] = act_apply1(c[q][r] + bz, act, (uint64_t)(io * H + colg));
+                    }
                 }
             }
         } else {
