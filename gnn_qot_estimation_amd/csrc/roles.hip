@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) 
         const Proj4 p{{rp<const float>(ro, 1), rp<const float>(ro, 3), rp<const float>(ro, 5), rp<const float>(ro, 7)},
                       {rp<const float>(ro, 2), rp<const float>(ro, 4), rp<const float>(ro, 6), rp<const float>(ro, 8)}};
         QOT_ROLE_H((int)ro.i[1], table_project_fwd_body<kH>(rp<const float>(ro, 0), p, rp<float>(ro, 9), rp<int64_t>(ro, 10),
-                                                            rp<int64_t>(ro, 11), vb, reinterpret_cast<float*>(dyn_lds)));
+                                                            rp<int64_t>(ro, 11), (int)ro.i[0], vb,
+                                                            reinterpret_cast<float*>(dyn_lds)));
         break;
     }
     case QOT_ROLE_GATHER3:
@@ -131,8 +132,9 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
         if (V <= 0 || (p[10] && !p[11])) return QOT_ERR_BADARG;
         if (!width_ok(H)) return QOT_ERR_UNSUPPORTED;
         for (int k = 0; k < 10; ++k) if (!p[k]) return QOT_ERR_BADARG;
-        *blocks = V;
-        *lds = (size_t)H * 4;
+        const int R = table_rows_per_block(V);
+        *blocks = (V + R - 1) / R;
+        *lds = (size_t)R * H * 4;
         return QOT_OK;
     }
     case QOT_ROLE_GATHER3: {
@@ -180,8 +182,9 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
         if (V <= 0) return QOT_ERR_BADARG;
         if (!width_ok(H)) return QOT_ERR_UNSUPPORTED;
         for (int k = 0; k < 9; ++k) if (!p[k]) return QOT_ERR_BADARG;
-        *blocks = 4 * H + V;
-        *lds = (size_t)(512 + 4 * H) * 4;
+        const int R = table_rows_per_block(V);
+        *blocks = 4 * H / R + (V + R - 1) / R;
+        *lds = (size_t)(512 * R + R * 4 * H) * 4;
         return QOT_OK;
     }
     default:

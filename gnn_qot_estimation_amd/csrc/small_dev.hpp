@@ -13,50 +13,78 @@ struct Proj4 {
 __device__ __forceinline__ const float* proj_w(const Proj4& p, int s) { return s == 0 ? p.w[0] : (s == 1 ? p.w[1] : (s == 2 ? p.w[2] : p.w[3])); }
 __device__ __forceinline__ const float* proj_b(const Proj4& p, int s) { return s == 0 ? p.b[0] : (s == 1 ? p.b[1] : (s == 2 ? p.b[2] : p.b[3])); }
 
-// out[v, s*H + o] = b_s[o] + sum_a table[v, a] * w_s[o, a];  one 256-thread workgroup per table row v; `row`: H floats of LDS
-template <int H>
-__device__ __forceinline__ void table_project_fwd_body(const float* __restrict__ table, const Proj4& p,
-                                                       float* __restrict__ out, int64_t* __restrict__ counter,
-                                                       int64_t* __restrict__ snapshot, int v, float* __restrict__ row) {
-    if (counter && v == 0 && threadIdx.x == 0) {   // as step_advance_kernel: this is the forward's first launch in table mode
-        const int64_t cc = counter[0] + 1;
-        counter[0] = cc;
-        snapshot[0] = cc;
+// Rows / outputs per workgroup.  One row per workgroup (R = 1) is what a small table wants (V = 100 at cfg2: latency);
+// a big one (V >= kTableBlockMinV: cfg4 / cfg5's 1000 nodes) is walked kTableBlock rows at a time so that a weight value
+// read from L2 serves kTableBlock rows -- with one row per workgroup every workgroup re-read all 4 H^2 weights: 1 GB of L2
+// traffic at V = 1000, H = 256 for a 0.5 GFLOP product (144 us forward, 238 us backward at cfg5).
+constexpr int kTableBlock = 8;
+constexpr int kTableBlockMinV = 512;
+__host__ __device__ inline int table_rows_per_block(int64_t V) { return V >= kTableBlockMinV ? kTableBlock : 1; }
+
+// out[v, s*H + o] = b_s[o] + sum_a table[v, a] * w_s[o, a];  one 256-thread workgroup per R table rows; `row`: R*H floats of LDS
+template <int H, int R>
+__device__ __forceinline__ void table_project_fwd_rows(const float* __restrict__ table, const Proj4& p,
+                                                       float* __restrict__ out, int V, int v0, float* __restrict__ row) {
+    for (int c = threadIdx.x; c < R * H; c += 256) {
+        const int r = c / H, a = c % H;
+        row[c] = v0 + r < V ? table[(int64_t)(v0 + r) * H + a] : 0.f;
     }
-    for (int c = threadIdx.x; c < H; c += 256) row[c] = table[(int64_t)v * H + c];
     __syncthreads();
     for (int c = threadIdx.x; c < 4 * H; c += 256) {
         const int s = c / H, o = c % H;
         const float* w = proj_w(p, s) + (int64_t)o * H;
-        float acc = proj_b(p, s)[o];
-#pragma unroll 8
+        float acc[R];
+        const float bz = proj_b(p, s)[o];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = bz;
+#pragma unroll 4
         for (int a = 0; a < H; a += 4) {
             const float4 ww = ld4(w + a);
-            acc = fmaf(ww.x, row[a], acc); acc = fmaf(ww.y, row[a + 1], acc);
-            acc = fmaf(ww.z, row[a + 2], acc); acc = fmaf(ww.w, row[a + 3], acc);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 xv = *reinterpret_cast<const float4*>(row + r * H + a);
+                acc[r] = fmaf(ww.x, xv.x, acc[r]); acc[r] = fmaf(ww.y, xv.y, acc[r]);
+                acc[r] = fmaf(ww.z, xv.z, acc[r]); acc[r] = fmaf(ww.w, xv.w, acc[r]);
+            }
         }
-        out[(int64_t)v * 4 * H + c] = acc;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (v0 + r < V) out[(int64_t)(v0 + r) * 4 * H + c] = acc[r];
     }
 }
 
-// blocks [0, 4H): weight + bias gradient of packed row c (= s*H + o):  gw[c, a] = sum_v gp[v, c] table[v, a]
-// blocks [4H, 4H + V): table gradient row v:                          gt[v, a] = sum_c gp[v, c] w_{s(c)}[o(c), a]
-// grads: gw [4H, H] | gb [4H]   (packed q|k|v|skip order).  256 threads = H columns x PH phases of the
-// reduction index (the loops are pure latency otherwise), phases meet in LDS in a fixed order.
-// virtual block vb of 4H + V; `lds`: 512 + 4H floats
 template <int H>
-__device__ __forceinline__ void table_project_bwd_body(const float* __restrict__ gp, const float* __restrict__ table,
-                                                       const Proj4& p, float* __restrict__ gtable,
-                                                       float* __restrict__ gw, float* __restrict__ gb, int V, int vb,
-                                                       float* __restrict__ lds) {
+__device__ __forceinline__ void table_project_fwd_body(const float* __restrict__ table, const Proj4& p,
+                                                       float* __restrict__ out, int64_t* __restrict__ counter,
+                                                       int64_t* __restrict__ snapshot, int V, int vb, float* __restrict__ row) {
+    if (counter && vb == 0 && threadIdx.x == 0) {   // as step_advance_kernel: this is the forward's first launch in table mode
+        const int64_t cc = counter[0] + 1;
+        counter[0] = cc;
+        snapshot[0] = cc;
+    }
+    if (table_rows_per_block(V) == 1) table_project_fwd_rows<H, 1>(table, p, out, V, vb, row);
+    else table_project_fwd_rows<H, kTableBlock>(table, p, out, V, vb * kTableBlock, row);
+}
+
+// Backward of the projection.  grads: gw [4H, H] | gb [4H] (packed q|k|v|skip order), gtable [V, H].
+//   weight part, one workgroup per CB packed rows c:  gw[c, a] = sum_v gp[v, c] table[v, a],  gb[c] = sum_v gp[v, c]
+//   table part, one workgroup per R table rows v:     gt[v, a] = sum_c gp[v, c] w_{s(c)}[o(c), a]
+// 256 threads = H columns x PH phases of the reduction index (the loops are pure latency otherwise), phases meet in LDS
+// in a fixed order.  Virtual blocks: [0, 4H / CB) weight part, then ceil(V / R) table part; CB = R = table_rows_per_block(V).
+// `lds`: 512 * CB + R * 4H floats
+template <int H, int CB>
+__device__ __forceinline__ void table_project_bwd_w(const float* __restrict__ gp, const float* __restrict__ table,
+                                                    float* __restrict__ gw, float* __restrict__ gb, int V, int c0,
+                                                    float* __restrict__ lds) {
     constexpr int PH = (H >= 256) ? 1 : 256 / H;
-    float* red = lds;
-    float* redb = lds + 256;
-    float* g = lds + 512;
+    float* red = lds;                 // [CB][256]
+    float* redb = lds + 256 * CB;     // [CB][256]
     const int a = threadIdx.x % H, ph = threadIdx.x / H;
-    float acc = 0.f, sb = 0.f;
-    if (vb < 4 * H) {
-        const int c = vb;
+    float acc[CB], sb[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) { acc[u] = 0.f; sb[u] = 0.f; }
+    if constexpr (CB == 1) {
+        const int c = c0;
         // (eight rows' operands requested before the first product: load -> use per trip serialises the round trips)
         int v = ph;
         for (; v + 7 * PH < V; v += 8 * PH) {
@@ -67,45 +95,112 @@ __device__ __forceinline__ void table_project_bwd_body(const float* __restrict__
                 tv[u] = table[(int64_t)(v + u * PH) * H + a];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc = fmaf(gv[u], tv[u], acc); sb += gv[u]; }
+            for (int u = 0; u < 8; ++u) { acc[0] = fmaf(gv[u], tv[u], acc[0]); sb[0] += gv[u]; }
         }
         for (; v < V; v += PH) {
             const float gv = gp[(int64_t)v * 4 * H + c];
-            acc = fmaf(gv, table[(int64_t)v * H + a], acc);
-            sb += gv;
-        }
-        red[threadIdx.x] = acc;
-        redb[threadIdx.x] = sb;
-        __syncthreads();
-        if (ph == 0) {
-            for (int k = 1; k < PH; ++k) { acc += red[k * H + a]; sb += redb[k * H + a]; }
-            gw[(int64_t)c * H + a] = acc;
-            if (a == 0) gb[c] = sb;
+            acc[0] = fmaf(gv, table[(int64_t)v * H + a], acc[0]);
+            sb[0] += gv;
         }
     } else {
-        const int v = vb - 4 * H;
-        for (int c = threadIdx.x; c < 4 * H; c += 256) g[c] = gp[(int64_t)v * 4 * H + c];
-        __syncthreads();
-        for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {              // 4H / PH = 16 H / 256 * ... trips: a multiple of 8 for every width
-            float wv[8];
+        static_assert(CB == 1 || CB == 8, "two float4 of gp per row");
+        int v = ph;
+        for (; v + 3 * PH < V; v += 4 * PH) {          // four rows in flight
+            float4 g0[4], g1[4];
+            float tv[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u * PH;
-                const int cc = c < 4 * H ? c : ph;
-                wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
+            for (int u = 0; u < 4; ++u) {
+                const float* gr = gp + (int64_t)(v + u * PH) * 4 * H + c0;
+                g0[u] = ld4(gr); g1[u] = ld4(gr + 4);
+                tv[u] = table[(int64_t)(v + u * PH) * H + a];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u * PH;
-                if (c < 4 * H) acc = fmaf(g[c], wv[u], acc);
+            for (int u = 0; u < 4; ++u) {
+                const float gv[8] = {g0[u].x, g0[u].y, g0[u].z, g0[u].w, g1[u].x, g1[u].y, g1[u].z, g1[u].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { acc[q] = fmaf(gv[q], tv[u], acc[q]); sb[q] += gv[q]; }
             }
         }
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (ph == 0) {
-            for (int k = 1; k < PH; ++k) acc += red[k * H + a];
-            gtable[(int64_t)v * H + a] = acc;
+        for (; v < V; v += PH) {
+            const float* gr = gp + (int64_t)v * 4 * H + c0;
+            const float4 g0 = ld4(gr), g1 = ld4(gr + 4);
+            const float tv = table[(int64_t)v * H + a];
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { acc[q] = fmaf(gv[q], tv, acc[q]); sb[q] += gv[q]; }
         }
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u) { red[u * 256 + threadIdx.x] = acc[u]; redb[u * 256 + threadIdx.x] = sb[u]; }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            float s = acc[u], t = sb[u];
+            for (int k = 1; k < PH; ++k) { s += red[u * 256 + k * H + a]; t += redb[u * 256 + k * H + a]; }
+            gw[(int64_t)(c0 + u) * H + a] = s;
+            if (a == 0) gb[c0 + u] = t;
+        }
+    }
+}
+
+template <int H, int R>
+__device__ __forceinline__ void table_project_bwd_t(const float* __restrict__ gp, const Proj4& p, float* __restrict__ gtable,
+                                                    int V, int v0, float* __restrict__ lds) {
+    constexpr int PH = (H >= 256) ? 1 : 256 / H;
+    float* red = lds;                 // [R][256]
+    float* g = lds + 512 * R;         // [R][4H]
+    const int a = threadIdx.x % H, ph = threadIdx.x / H;
+    for (int c = threadIdx.x; c < R * 4 * H; c += 256) {
+        const int r = c / (4 * H);
+        g[c] = v0 + r < V ? gp[(int64_t)(v0 + r) * 4 * H + c % (4 * H)] : 0.f;
+    }
+    __syncthreads();
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {              // 4H / PH trips: a multiple of 8 for every width
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * PH;
+            const int cc = c < 4 * H ? c : ph;
+            wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * PH;
+            if (c < 4 * H) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fmaf(g[r * 4 * H + c], wv[u], acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[r * 256 + threadIdx.x] = acc[r];
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = acc[r];
+            for (int k = 1; k < PH; ++k) s += red[r * 256 + k * H + a];
+            if (v0 + r < V) gtable[(int64_t)(v0 + r) * H + a] = s;
+        }
+    }
+}
+
+template <int H>
+__device__ __forceinline__ void table_project_bwd_body(const float* __restrict__ gp, const float* __restrict__ table,
+                                                       const Proj4& p, float* __restrict__ gtable,
+                                                       float* __restrict__ gw, float* __restrict__ gb, int V, int vb,
+                                                       float* __restrict__ lds) {
+    if (table_rows_per_block(V) == 1) {
+        if (vb < 4 * H) table_project_bwd_w<H, 1>(gp, table, gw, gb, V, vb, lds);
+        else table_project_bwd_t<H, 1>(gp, p, gtable, V, vb - 4 * H, lds);
+    } else {
+        constexpr int NW = 4 * H / kTableBlock;
+        if (vb < NW) table_project_bwd_w<H, kTableBlock>(gp, table, gw, gb, V, vb * kTableBlock, lds);
+        else table_project_bwd_t<H, kTableBlock>(gp, p, gtable, V, (vb - NW) * kTableBlock, lds);
     }
 }
 
