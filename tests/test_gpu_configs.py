@@ -46,6 +46,30 @@ def test_cfg3_shape_three_layer_c128_train_fwd_bwd_running_stats(cuda_device):
         assert int(h.num_batches_tracked) == int(r.num_batches_tracked) == 1
 
 
+def test_cfg3_logits_from_the_projection_epilogue_equal_the_separate_pass(cuda_device, monkeypatch):
+    """The attention logits formed in the projections' epilogues (qot_gemm_nt_logits / qot_skinny_linear_fwd_logits, C = 128)
+    against the separate pass over z (QOT_NO_FUSED_LOGITS=1): same model, same batch, outputs and every gradient."""
+    import copy
+    batch = S.lightpath_batch(48).to(cuda_device)
+    _, hip = _models("lp", cuda_device, in_channels=5, hidden_channels=128, output_dim=3, is_lut_index=1,
+                     dropout_p=0.0, num_layers=3)
+    hip2 = copy.deepcopy(hip)
+    hip.train(); hip2.train()
+    out1, lb1 = hip(batch)
+    F.smooth_l1_loss(out1, batch.y[lb1]).backward()
+    monkeypatch.setenv("QOT_NO_FUSED_LOGITS", "1")
+    out2, lb2 = hip2(batch)
+    F.smooth_l1_loss(out2, batch.y[lb2]).backward()
+    assert torch.equal(lb1, lb2)
+    assert rel_err(out1, out2) <= 1e-5
+    scale = max(float(p.grad.abs().max()) for p in hip2.parameters() if p.grad is not None)
+    for (n1, p1), (_, p2) in zip(hip.named_parameters(), hip2.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), n1
+        if p1.grad is not None:
+            # (conv biases in front of a train-mode BatchNorm have analytically zero gradients: rounding residue only)
+            assert float((p1.grad - p2.grad).abs().max()) <= max(2e-5 * float(p2.grad.abs().max()), 1e-6 * scale), n1
+
+
 def test_cfg3_shape_three_layer_c128_eval(cuda_device):
     batch = S.lightpath_batch(48, first_graph=100)
     ref, hip = _models("lp", cuda_device, in_channels=5, hidden_channels=128, output_dim=3, is_lut_index=1,
