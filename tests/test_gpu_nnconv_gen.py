@@ -1,7 +1,8 @@
 """Width-generic fused NNConv kernels (csrc/nnconv_gen.hip) through the C ABI, against an fp64 restatement of the
 operator contract (App. B.2 algebra: out = bias + A @ Wcat) and its autograd: forward, adjoint (grad_x), weight
 gradient in the parameters' layouts, gradient of the edge MLP's first layer.  Cases: random graph, a 300-in-edge hub
-(more edges in one 32-row tile than the per-edge partial buffer holds -> several segments), edge_dim 2, no edges,
+(more edges in one 32-row tile than the H = 64 grad-h kernel stages in LDS, more than 8 slots per lane group in the generic
+one), a 700-in-edge hub (beyond every kernel's staged edges: the direct paths of the grad-h kernels), edge_dim 2, no edges,
 N not a multiple of 32; every supported width, plus the generic kernel at H = 64 beside the tuned one."""
 import pytest
 import torch
