@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) 
     case QOT_ROLE_TABLE_PROJECT_FWD: {
         const Proj4 p{{rp<const float>(ro, 1), rp<const float>(ro, 3), rp<const float>(ro, 5), rp<const float>(ro, 7)},
                       {rp<const float>(ro, 2), rp<const float>(ro, 4), rp<const float>(ro, 6), rp<const float>(ro, 8)}};
-        QOT_ROLE_H((int)ro.i[1], table_project_fwd_body<kH>(rp<const float>(ro, 0), p, rp<float>(ro, 9), rp<int64_t>(ro, 10),
-                                                            rp<int64_t>(ro, 11), (int)ro.i[0], vb,
-                                                            reinterpret_cast<float*>(dyn_lds)));
+        QOT_ROLE_H((int)ro.i[1], table_project_fwd_body<kH, 1>(rp<const float>(ro, 0), p, rp<float>(ro, 9), rp<int64_t>(ro, 10),
+                                                               rp<int64_t>(ro, 11), (int)ro.i[0], vb,
+                                                               reinterpret_cast<float*>(dyn_lds)));
         break;
     }
     case QOT_ROLE_GATHER3:
@@ -92,14 +92,31 @@ __global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) 
     case QOT_ROLE_TABLE_PROJECT_BWD: {
         const Proj4 p{{rp<const float>(ro, 2), rp<const float>(ro, 3), rp<const float>(ro, 4), rp<const float>(ro, 5)},
                       {nullptr, nullptr, nullptr, nullptr}};
-        QOT_ROLE_H((int)ro.i[1], table_project_bwd_body<kH>(rp<const float>(ro, 0), rp<const float>(ro, 1), p, rp<float>(ro, 6),
-                                                            rp<float>(ro, 7), rp<float>(ro, 8), (int)ro.i[0], vb,
-                                                            reinterpret_cast<float*>(dyn_lds)));
+        QOT_ROLE_H((int)ro.i[1], table_project_bwd_body<kH, 1>(rp<const float>(ro, 0), rp<const float>(ro, 1), p, rp<float>(ro, 6),
+                                                               rp<float>(ro, 7), rp<float>(ro, 8), (int)ro.i[0], vb,
+                                                               reinterpret_cast<float*>(dyn_lds)));
         break;
     }
     default:
         break;
     }
+}
+
+// Table projection of a big table (V >= kTableBlockMinV): kTableBlock rows per workgroup, kernels of their own (their
+// register needs would otherwise be every role's; at those sizes a launch more is nothing).
+template <int H>
+__global__ __launch_bounds__(256) void table_project_fwd_block_kernel(const float* __restrict__ table, Proj4 p,
+                                                                      float* __restrict__ out, int64_t* __restrict__ counter,
+                                                                      int64_t* __restrict__ snapshot, int V) {
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    table_project_fwd_body<H, kTableBlock>(table, p, out, counter, snapshot, V, (int)blockIdx.x, reinterpret_cast<float*>(dyn_lds));
+}
+template <int H>
+__global__ __launch_bounds__(256) void table_project_bwd_block_kernel(const float* __restrict__ gp, const float* __restrict__ table,
+                                                                      Proj4 p, float* __restrict__ gtable, float* __restrict__ gw,
+                                                                      float* __restrict__ gb, int V) {
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    table_project_bwd_body<H, kTableBlock>(gp, table, p, gtable, gw, gb, V, (int)blockIdx.x, reinterpret_cast<float*>(dyn_lds));
 }
 
 }  // namespace qot
@@ -132,7 +149,7 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
         if (V <= 0 || (p[10] && !p[11])) return QOT_ERR_BADARG;
         if (!width_ok(H)) return QOT_ERR_UNSUPPORTED;
         for (int k = 0; k < 10; ++k) if (!p[k]) return QOT_ERR_BADARG;
-        const int R = table_rows_per_block(V);
+        const int R = table_rows_per_block(V);          // R > 1: launched on its own (launch_heavy_role)
         *blocks = (V + R - 1) / R;
         *lds = (size_t)R * H * 4;
         return QOT_OK;
@@ -192,26 +209,55 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
     }
 }
 
+// a table projection over >= kTableBlockMinV rows: its own launch (see table_project_*_block_kernel)
+static int launch_heavy_role(const qot_role_t& ro, int64_t blocks, size_t lds, hipStream_t stream) {
+    const int V = (int)ro.i[0];
+    auto P = [&](int k) { return const_cast<void*>(ro.p[k]); };
+    if (ro.kind == QOT_ROLE_TABLE_PROJECT_FWD) {
+        const Proj4 p{{(const float*)P(1), (const float*)P(3), (const float*)P(5), (const float*)P(7)},
+                      {(const float*)P(2), (const float*)P(4), (const float*)P(6), (const float*)P(8)}};
+        QOT_ROLE_H((int)ro.i[1], (table_project_fwd_block_kernel<kH><<<(int)blocks, 256, lds, stream>>>(
+                                      (const float*)P(0), p, (float*)P(9), (int64_t*)P(10), (int64_t*)P(11), V)));
+    } else {
+        const Proj4 p{{(const float*)P(2), (const float*)P(3), (const float*)P(4), (const float*)P(5)},
+                      {nullptr, nullptr, nullptr, nullptr}};
+        QOT_ROLE_H((int)ro.i[1], (table_project_bwd_block_kernel<kH><<<(int)blocks, 256, lds, stream>>>(
+                                      (const float*)P(0), (const float*)P(1), p, (float*)P(6), (float*)P(7), (float*)P(8), V)));
+    }
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" int qot_run_roles(const qot_role_t* roles, int n_roles, qot_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_roles < 0 || n_roles > QOT_MAX_ROLES || (n_roles > 0 && !roles)) return QOT_ERR_BADARG;
     if (n_roles == 0) return QOT_OK;
     RoleTable t;
-    t.n = n_roles;
+    t.n = 0;
     size_t lds = 0;
     int64_t total = 0;
+    int n_light = 0;
     for (int r = 0; r < n_roles; ++r) {
-        t.role[r] = roles[r];
+        qot_role_t ro = roles[r];
         int64_t blocks;
         size_t need;
-        const int rc = plan_role(t.role[r], &blocks, &need);
+        const int rc = plan_role(ro, &blocks, &need);
         if (rc != QOT_OK) return rc;
-        t.first[r] = (int)total;
+        if ((ro.kind == QOT_ROLE_TABLE_PROJECT_FWD || ro.kind == QOT_ROLE_TABLE_PROJECT_BWD) && table_rows_per_block(ro.i[0]) > 1) {
+            const int hrc = launch_heavy_role(ro, blocks, need, stream);     // jobs of one call are independent: any order
+            if (hrc != QOT_OK) return hrc;
+            continue;
+        }
+        t.role[n_light] = ro;
+        t.first[n_light] = (int)total;
+        ++n_light;
         total += blocks;
         if (total > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
         if (need > lds) lds = need;
     }
-    for (int r = n_roles; r <= QOT_MAX_ROLES; ++r) t.first[r] = (int)total;
+    if (n_light == 0) return QOT_OK;
+    t.n = n_light;
+    for (int r = n_light; r <= QOT_MAX_ROLES; ++r) t.first[r] = (int)total;
     {   // dynamic LDS above 64 KB has to be allowed once (the first call is outside any graph capture)
         static size_t allowed = 64 * 1024;
         if (lds > allowed) {

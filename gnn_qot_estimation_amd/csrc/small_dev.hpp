@@ -31,10 +31,15 @@ __device__ __forceinline__ void table_project_fwd_rows(const float* __restrict__
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 4 * H; c += 256) {
-        const int s = c / H, o = c % H;
+        // (H >= 64: the projection index is the same for a whole wave -- said so, the pointer selects below are scalar;
+        // as a per-lane index the compiler turned them into an indexed read of a copy of the pointers in scratch)
+        const int s = H >= 64 ? __builtin_amdgcn_readfirstlane(c / H) : c / H, o = c % H;
         const float* w = proj_w(p, s) + (int64_t)o * H;
         float acc[R];
-        const float bz = proj_b(p, s)[o];
+        // (four loads and a value select: a select of the four bias POINTERS was compiled into an indexed read of a copy of
+        // them in scratch)
+        const float b0 = p.b[0][o], b1 = p.b[1][o], b2 = p.b[2][o], b3 = p.b[3][o];
+        const float bz = s == 0 ? b0 : (s == 1 ? b1 : (s == 2 ? b2 : b3));
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = bz;
 #pragma unroll 4
@@ -53,7 +58,9 @@ __device__ __forceinline__ void table_project_fwd_rows(const float* __restrict__
     }
 }
 
-template <int H>
+// R = 1 inside the multi-role kernel, R = kTableBlock in a kernel of its own (roles.hip): the blocked bodies' registers
+// (150 + scratch against 74) must not set the occupancy of every other job of the multi-role launch.
+template <int H, int R>
 __device__ __forceinline__ void table_project_fwd_body(const float* __restrict__ table, const Proj4& p,
                                                        float* __restrict__ out, int64_t* __restrict__ counter,
                                                        int64_t* __restrict__ snapshot, int V, int vb, float* __restrict__ row) {
@@ -62,8 +69,7 @@ __device__ __forceinline__ void table_project_fwd_body(const float* __restrict__
         counter[0] = cc;
         snapshot[0] = cc;
     }
-    if (table_rows_per_block(V) == 1) table_project_fwd_rows<H, 1>(table, p, out, V, vb, row);
-    else table_project_fwd_rows<H, kTableBlock>(table, p, out, V, vb * kTableBlock, row);
+    table_project_fwd_rows<H, R>(table, p, out, V, vb * R, row);
 }
 
 // Backward of the projection.  grads: gw [4H, H] | gb [4H] (packed q|k|v|skip order), gtable [V, H].
@@ -189,19 +195,14 @@ __device__ __forceinline__ void table_project_bwd_t(const float* __restrict__ gp
     }
 }
 
-template <int H>
+template <int H, int R>
 __device__ __forceinline__ void table_project_bwd_body(const float* __restrict__ gp, const float* __restrict__ table,
                                                        const Proj4& p, float* __restrict__ gtable,
                                                        float* __restrict__ gw, float* __restrict__ gb, int V, int vb,
                                                        float* __restrict__ lds) {
-    if (table_rows_per_block(V) == 1) {
-        if (vb < 4 * H) table_project_bwd_w<H, 1>(gp, table, gw, gb, V, vb, lds);
-        else table_project_bwd_t<H, 1>(gp, p, gtable, V, vb - 4 * H, lds);
-    } else {
-        constexpr int NW = 4 * H / kTableBlock;
-        if (vb < NW) table_project_bwd_w<H, kTableBlock>(gp, table, gw, gb, V, vb * kTableBlock, lds);
-        else table_project_bwd_t<H, kTableBlock>(gp, p, gtable, V, (vb - NW) * kTableBlock, lds);
-    }
+    constexpr int NW = 4 * H / R;
+    if (vb < NW) table_project_bwd_w<H, R>(gp, table, gw, gb, V, vb * R, lds);
+    else table_project_bwd_t<H, R>(gp, p, gtable, V, (vb - NW) * R, lds);
 }
 
 // ---- out[i] = concat(s0[0:n0], s1[0:n1], s2)[idx[i]] (0 where idx[i] < 0) ------------------------------------------
