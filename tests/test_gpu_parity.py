@@ -481,8 +481,9 @@ def test_fused_smooth_l1_matches_torch(n, beta):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,V", [(16, 75), (64, 100), (128, 33)])
+@pytest.mark.parametrize("H,V", [(16, 75), (64, 100), (128, 33), (64, 517), (256, 1000), (32, 512)])
 def test_table_projection_matches_linear(H, V):
+    """V >= 512: the blocked kernels (8 table rows / 8 packed weight rows per workgroup, roles.hip), V not a multiple of 8."""
     from gnn_qot_estimation_amd import functional as QF
     torch.manual_seed(2)
     dev = "cuda"
