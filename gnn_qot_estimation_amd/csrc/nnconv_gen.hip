@@ -39,103 +39,13 @@ __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&v)[CPL]
     }
 }
 
-// Gather of one destination's operand blocks by its 8-lane group, CPL channels per lane starting at channel
-// `cbase` of the rows (x + row*ldx + cbase).  Lane `sub` prefetches in-edge `sub` of a batch of eight (source, edge
-// id, features) and evaluates that edge's h = relu(W1 ea + b1) once; broadcasts on the DPP path; four source rows in
-// flight.  acc[kk] (kk < K): sum_e h_e[kk] x_j, acc[K]: sum_e x_j, scaled by the destination's 1/deg (forward) or
-// with 1/deg of the gathered end folded into h (TRANSPOSE); root = the node's own row.  i >= N gives zeros.
-template <int D, int CPL, bool TRANSPOSE>
-__device__ __forceinline__ void gen_gather(const float* __restrict__ x, int ldx, int cbase, const float* __restrict__ ea,
-                                           const float* __restrict__ w1, const float* __restrict__ b1,
-                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                           const int32_t* __restrict__ eidx, const float* __restrict__ invdeg, int64_t i,
-                                           int64_t N, int lo, int hi_, float (&acc)[2 * D + 1][CPL], float (&root)[CPL]) {
-    constexpr int K = 2 * D;
-    const int sub = threadIdx.x & 7;
-#pragma unroll
-    for (int kk = 0; kk <= K; ++kk)
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) acc[kk][c] = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) root[c] = 0.f;
-    int beg = 0, end = 0;
-    float srow = 0.f;
-    if (i < N) {
-        beg = rowptr[i]; end = rowptr[i + 1];
-        if (beg < lo) beg = lo;
-        if (end > hi_) end = hi_;
-        if (!TRANSPOSE) srow = invdeg[i];
-        ldv<CPL>(x + i * ldx + cbase, root);
-    }
-    const bool upper = (sub & 4) != 0;
-    for (int base = beg; base < end; base += 8) {
-        const int p = base + sub;
-        int myj = (int)i;
-        float myh[K], mysc = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) myh[kk] = 0.f;
-        if (p < end) {
-            myj = col[p];
-            const int64_t e = eidx[p];
-            float ee[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) ee[d] = ea[e * D + d];
-            mysc = TRANSPOSE ? invdeg[myj] : 1.0f;
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                float h = b1[kk];
-#pragma unroll
-                for (int d = 0; d < D; ++d) h = fmaf(w1[kk * D + d], ee[d], h);
-                myh[kk] = fmaxf(h, 0.f) * mysc;
-            }
-        }
-        const int cnt = (end - base < 8) ? end - base : 8;
-        // dead slots of a batch (lane p >= end) carry h = 0 and scale = 0 from the prefetch above, so their terms vanish
-        // without per-use selects; their row load is pointed at the destination's own row (always a valid address, and
-        // a non-finite value there already reaches this destination through its root term)
-#define QOT_GEN_EDGE4(U0)                                                                                \
-        {                                                                                                \
-            float xv[4][CPL];                                                                            \
-            float sc[4];                                                                                 \
-            int jj[4];                                                                                   \
-            jj[0] = group8_bcast<U0 + 0>(myj, upper); jj[1] = group8_bcast<U0 + 1>(myj, upper);          \
-            jj[2] = group8_bcast<U0 + 2>(myj, upper); jj[3] = group8_bcast<U0 + 3>(myj, upper);          \
-            sc[0] = group8_bcast<U0 + 0>(mysc, upper); sc[1] = group8_bcast<U0 + 1>(mysc, upper);        \
-            sc[2] = group8_bcast<U0 + 2>(mysc, upper); sc[3] = group8_bcast<U0 + 3>(mysc, upper);        \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
-                ldv<CPL>(x + (int64_t)jj[u] * ldx + cbase, xv[u]);                                       \
-            _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                           \
-                const float h0 = group8_bcast<U0 + 0>(myh[kk]), h1 = group8_bcast<U0 + 1>(myh[kk]);      \
-                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h0, xv[0][c], acc[kk][c]); \
-                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h1, xv[1][c], acc[kk][c]); \
-            }                                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                \
-                _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
-            /* four rows stay in flight, the vector work is skipped in pairs (VALU time is MFMA time here) */ \
-            if (cnt > U0 + 2) {                                                                          \
-                _Pragma("unroll") for (int kk = 0; kk < K; ++kk) {                                       \
-                    const float h2 = group8_bcast<U0 + 2>(myh[kk]), h3 = group8_bcast<U0 + 3>(myh[kk]);  \
-                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h2, xv[2][c], acc[kk][c]); \
-                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[kk][c] = fmaf(h3, xv[3][c], acc[kk][c]); \
-                }                                                                                        \
-                _Pragma("unroll") for (int u = 2; u < 4; ++u)                                            \
-                    _Pragma("unroll") for (int c = 0; c < CPL; ++c) acc[K][c] = fmaf(sc[u], xv[u][c], acc[K][c]); \
-            }                                                                                            \
-        }
-        QOT_GEN_EDGE4(0)
-        if (cnt > 4) QOT_GEN_EDGE4(4)
-#undef QOT_GEN_EDGE4
-    }
-    if (!TRANSPOSE) {
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk)
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) acc[kk][c] *= srow;
-    }
-}
-
-// gen_gather with the batch's per-edge values (source row, scale, h[K]) exchanged through LDS instead of DPP
-// broadcasts (r03).  Every lane of an 8-lane group still prefetches one in-edge of a batch of eight and evaluates
+// Gather of one destination's operand blocks by its 8-lane group, CPL channels per lane starting at channel `cbase` of the
+// rows (x + row*ldx + cbase).  Lane `sub` prefetches in-edge `sub` of a batch of eight (source, edge id, features) and
+// evaluates that edge's h = relu(W1 ea + b1) once; four source rows in flight.  acc[kk] (kk < K): sum_e h_e[kk] x_j,
+// acc[K]: sum_e x_j, scaled by the destination's 1/deg (forward) or with 1/deg of the gathered end folded into h
+// (TRANSPOSE); root = the node's own row.  i >= N gives zeros.
+// The batch's per-edge values (source row, scale, h[K]) are exchanged through LDS (r03; r02 broadcast them with DPP moves).
+// Every lane of an 8-lane group still prefetches one in-edge of a batch of eight and evaluates
 // its h once; it then WRITES {j, scale, h[0..K)} as float4 chunks to the group's exchange slots and the group reads
 // edge u's chunks back as LDS broadcasts.  The DPP form costs 2 VALU moves per value and edge -- 20 values, 40 moves
 // against 36 (CPL = 4) or 72 (CPL = 8) FMAs -- and vector instructions of a gathering wave take issue cycles away
