@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 7          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 8          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -51,6 +51,16 @@ SIGNATURES = {
                                  _p, _f, _f, _u64, _p, _p, _p, _int, _i64, _p, _i64, _int, _int, _p]),
     "qot_tconv_bwd_src": (_int, [_p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _i64, _p, _i64, _int,
                                  _p]),
+    "qot_tconv_graph_supported": (_int, [_int, _int, _int, _int]),
+    "qot_tconv_graph_ldm": (_int, [_int]),
+    "qot_tconv_graph_row_floats": (_sz, [_int, _int, _int]),
+    "qot_tconv_bwd_graph_blocks": (_int, [_i64]),
+    "qot_table_scores": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _int, _p]),
+    "qot_tconv_fwd_graph": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _int, _int, _int, _f, _f,
+                                   _u64, _p, _p]),
+    "qot_tconv_bwd_graph": (_int, [_p, _p, _f, _f, _u64, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64,
+                                   _int, _int, _int, _p]),
+    "qot_table_project_bwd_scores": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
                                 _int, _f, _f, _u64, _p, _p]),
@@ -123,7 +133,8 @@ SIGNATURES = {
 }
 
 MAX_ROLES = 12           # include/qot_gnn.h: QOT_MAX_ROLES
-ROLE_CSR_BY_GRAPH, ROLE_TABLE_PROJECT_FWD, ROLE_GATHER3, ROLE_SUM_ROWS, ROLE_NNCONV_FINALIZE64, ROLE_TABLE_PROJECT_BWD = range(1, 7)
+(ROLE_CSR_BY_GRAPH, ROLE_TABLE_PROJECT_FWD, ROLE_GATHER3, ROLE_SUM_ROWS, ROLE_NNCONV_FINALIZE64, ROLE_TABLE_PROJECT_BWD,
+ ROLE_TABLE_SCORES, ROLE_TABLE_PROJECT_BWD_SCORES) = range(1, 9)
 
 
 class Role(C.Structure):

@@ -183,6 +183,28 @@ __device__ __forceinline__ int xcd_block(int orig, int nwg) {
 
 inline int grid_for(int64_t work, int per_block) { return (int)((work + per_block - 1) / per_block); }
 
+// Dynamic LDS above 64 KB has to be allowed per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize is a
+// per-device attribute).  `allowed` is the caller's static table, one entry per device ordinal, zero-initialised (= the
+// 64 KB default).  The first call for a size happens outside any stream capture (every captured step has been through
+// an eager step).  Returns QOT_OK, QOT_ERR_UNSUPPORTED when the runtime refuses the size (the launch would otherwise
+// fail later with a less telling error), or the HIP error of hipGetDevice.
+constexpr int kMaxDevices = 64;
+inline int ensure_dyn_lds(const void* func, size_t bytes, size_t (&allowed)[kMaxDevices]) {
+    if (bytes <= 64 * 1024) return QOT_OK;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return QOT_ERR_UNSUPPORTED;
+    if (bytes <= allowed[dev]) return QOT_OK;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return QOT_ERR_UNSUPPORTED;
+    }
+    allowed[dev] = bytes;
+    return QOT_OK;
+}
+
 }  // namespace qot
 
 #define QOT_DISPATCH_H(H, ...)                  \

@@ -469,12 +469,9 @@ extern "C" int qot_head_train(const float* x, const int32_t* ptr, const float* w
     const float inv_n = 1.0f / ((float)B * (float)O);
     QOT_HEAD_H(H, {
         const size_t lds = (size_t)(kHeadRowsCap * kH + kH * (kH + 1) + 8 * kH) * sizeof(float);
-        static size_t allowed = 48 * 1024;
-        if (lds > allowed) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_train_kernel<kH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            allowed = lds;
-        }
+        static size_t allowed[kMaxDevices];                 // per device: the attribute is
+        const int lrc = ensure_dyn_lds(reinterpret_cast<const void*>(head_train_kernel<kH>), lds, allowed);
+        if (lrc != QOT_OK) return lrc;
         head_train_kernel<kH><<<blocks, 256, lds, stream>>>(x, ptr, w0, b0, w3, b3, target, beta, inv_n, out, grad_out,
                                                             loss_rows, grad_x, workspace, B, O, ap, fold, in_ap);
     });

@@ -10,7 +10,8 @@
 //
 // Used by the host side for
 //   forward prologue   {graph index of a block-diagonal batch | embedding-table projection (+ dropout counter) |
-//                       NNConv operand packing}                        -- three launches before (topological.py)
+//                       NNConv operand packing | r04: score matrix M and P of TransformerConv's graph form}
+//                                                                      -- three launches before (topological.py)
 //   backward epilogue  stage 1 {read-out partial sums | NNConv slab + grad-h sums | lin_edge level-1 sums | table
 //                       gradient row sum}, stage 2 {table projection backward | lin_edge level-2 sum}
 //                                                                      -- seven launches before (functional.py)
@@ -21,6 +22,7 @@
 #include "nnconv_finalize_dev.hpp"
 #include "reduce_dev.hpp"
 #include "small_dev.hpp"
+#include "tconv_graph_dev.hpp"
 
 namespace qot {
 
@@ -95,6 +97,22 @@ __global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) 
         QOT_ROLE_H((int)ro.i[1], table_project_bwd_body<kH, 1>(rp<const float>(ro, 0), rp<const float>(ro, 1), p, rp<float>(ro, 6),
                                                                rp<float>(ro, 7), rp<float>(ro, 8), (int)ro.i[0], vb,
                                                                reinterpret_cast<float*>(dyn_lds)));
+        break;
+    }
+    case QOT_ROLE_TABLE_SCORES:
+        QOT_ROLE_H((int)ro.i[1], table_scores_body<kH>(rp<const float>(ro, 0), rp<const float>(ro, 1), rp<const float>(ro, 2),
+                                                       rp<const float>(ro, 3), rp<const float>(ro, 4), rp<const float>(ro, 5),
+                                                       rp<float>(ro, 6), rp<float>(ro, 7), (int)ro.i[0], (int)ro.i[2], vb,
+                                                       reinterpret_cast<float*>(dyn_lds)));
+        break;
+    case QOT_ROLE_TABLE_PROJECT_BWD_SCORES: {
+        const Proj4 p{{rp<const float>(ro, 4), rp<const float>(ro, 5), rp<const float>(ro, 6), rp<const float>(ro, 7)},
+                      {nullptr, nullptr, nullptr, nullptr}};
+        QOT_ROLE_H((int)ro.i[2], table_project_bwd_scores_body<kH>(rp<const float>(ro, 0), rp<const float>(ro, 1),
+                                                                   rp<const float>(ro, 2), rp<const float>(ro, 3), p,
+                                                                   rp<float>(ro, 8), rp<float>(ro, 9), rp<float>(ro, 10),
+                                                                   (int)ro.i[0], (int)ro.i[1], (int)ro.i[3], vb,
+                                                                   reinterpret_cast<float*>(dyn_lds)));
         break;
     }
     default:
@@ -204,6 +222,24 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
         *lds = (size_t)(512 * R + R * 4 * H) * 4;
         return QOT_OK;
     }
+    case QOT_ROLE_TABLE_SCORES: {
+        const int64_t n = i[0], H = i[1], D = i[2];
+        if (n <= 0 || D <= 0) return QOT_ERR_BADARG;
+        if (!width_ok(H) || D > 8) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 8; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = (n + kScoreRows - 1) / kScoreRows;
+        *lds = (size_t)kScoreRows * (3 * H + 1) * 4;
+        return QOT_OK;
+    }
+    case QOT_ROLE_TABLE_PROJECT_BWD_SCORES: {
+        const int64_t V = i[0], n = i[1], H = i[2], D = i[3];
+        if (V <= 0 || n <= 0 || n > V || D <= 0) return QOT_ERR_BADARG;
+        if (!width_ok(H) || D > 8 || table_rows_per_block(V) > 1) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 11; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = 4 * H + V;
+        *lds = (size_t)(512 + (4 * H > n ? 4 * H : n)) * 4;
+        return QOT_OK;
+    }
     default:
         return QOT_ERR_BADARG;
     }
@@ -258,13 +294,10 @@ extern "C" int qot_run_roles(const qot_role_t* roles, int n_roles, qot_stream_t 
     if (n_light == 0) return QOT_OK;
     t.n = n_light;
     for (int r = n_light; r <= QOT_MAX_ROLES; ++r) t.first[r] = (int)total;
-    {   // dynamic LDS above 64 KB has to be allowed once (the first call is outside any graph capture)
-        static size_t allowed = 64 * 1024;
-        if (lds > allowed) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roles_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            allowed = lds;
-        }
+    {   // dynamic LDS above 64 KB has to be allowed once per device (the first call is outside any graph capture)
+        static size_t allowed[kMaxDevices];
+        const int lrc = ensure_dyn_lds(reinterpret_cast<const void*>(roles_kernel), lds, allowed);
+        if (lrc != QOT_OK) return lrc;
     }
     roles_kernel<<<(int)total, 256, lds, stream>>>(t);
     QOT_LAUNCH_CHECK();

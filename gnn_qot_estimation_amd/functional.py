@@ -371,6 +371,117 @@ class TConvFn(torch.autograd.Function):
         return gq, None, gwe_flat.view(H, D), None, None, None
 
 
+def tconv_graph_plan(table, H: int, D: int, graph: GraphIndex, maps):
+    """``(n, B, max_e)`` when TransformerConv's GRAPH form takes this batch, else ``None``: table mode with ``node_ids ==
+    arange(n)`` in every graph (``maps``), the index built graph by graph (block-diagonal, slices verified), ``n <= 128``
+    and the LDS images of ``csrc/tconv_graph.hip`` fit, a table the one-row projection bodies take (V < 512)."""
+    if maps is None or graph.sizes is None or os.environ.get("QOT_NO_TCONV_GRAPH"):
+        return None
+    B, n = maps[3]
+    if B <= 0 or n <= 0 or graph.num_nodes != B * n or table.shape[0] >= 512 or n > table.shape[0]:
+        return None
+    max_e = int(graph.sizes[1])
+    if not _lib.load().qot_tconv_graph_supported(int(n), max_e, int(H), int(D)):
+        return None
+    return int(n), int(B), max_e
+
+
+def tconv_graph_prepare(table, wq, bq, wk, bk, wv, bv, ws, bs, w_edge, n: int, step_pair=None, group=None):
+    """``(t4, M, P)`` of the graph form from the current parameters: the projected table ``[V, 4H]`` (as
+    ``TableProjectFn``; the launch also advances the dropout counter of ``step_pair``), the score matrix ``M = T_q T_k^T /
+    sqrt(H)`` ``[n, ldm]`` and ``P = T_q W_e / sqrt(H)`` ``[n, D]``.  Two independent jobs: with ``group`` they join the
+    forward prologue's multi-role launch (valid after ``group.run()``)."""
+    ts = [_f32c(t.detach()) for t in (table, wq, bq, wk, bk, wv, bv, ws, bs, w_edge)]
+    require_cuda(*ts)
+    table, wq, bq, wk, bk, wv, bv, ws, bs, w_edge = ts
+    V, H = table.shape
+    D = w_edge.shape[1]
+    dev = table.device
+    t4 = torch.empty(V, 4 * H, dtype=torch.float32, device=dev)
+    M = torch.empty(n, _lib.load().qot_tconv_graph_ldm(n), dtype=torch.float32, device=dev)
+    Pm = torch.empty(n, D, dtype=torch.float32, device=dev)
+    cnt, snap = step_pair if step_pair is not None else (None, None)
+    if group is not None:
+        group.add(_lib.ROLE_TABLE_PROJECT_FWD, (table, wq, bq, wk, bk, wv, bv, ws, bs, t4, cnt, snap), (V, H))
+        group.add(_lib.ROLE_TABLE_SCORES, (table, wq, bq, wk, bk, w_edge, M, Pm), (n, H, D))
+    else:
+        _lib.call("qot_table_project_fwd", table, wq, bq, wk, bk, wv, bv, ws, bs, t4, V, H, P(cnt), P(snap))
+        _lib.call("qot_table_scores", table, wq, bq, wk, bk, w_edge, M, Pm, n, H, D)
+    return t4, M, Pm
+
+
+class TConvGraphFn(torch.autograd.Function):
+    """TransformerConv of ``x = table[arange(n)]`` per graph in the GRAPH form (``csrc/tconv_graph.hip``): embedding
+    lookup, the four projections, the edge softmax / aggregation, the fused ``dropout(leaky_relu(.))`` and the whole
+    backward down to the gradients of the table and of the nine projection parameters
+    (``topological_training/models.py:51-55`` and its autograd).  ``pre = (t4, M, P)`` from ``tconv_graph_prepare`` (the
+    forward prologue's launch).  One kernel forward; backward one kernel + the two epilogue launches of the step."""
+
+    @staticmethod
+    def forward(ctx, table, wq, bq, wk, bk, wv, bv, ws, bs, w_edge, edge_attr, pre, graph: GraphIndex, maps, plan, act=None):
+        t4, M, Pm = pre
+        n, B, max_e = plan
+        edge_attr, w_edge_c = _f32c(edge_attr), _f32c(w_edge.detach())
+        require_cuda(edge_attr, t4, M, Pm)
+        H, D = table.shape[1], w_edge.shape[1]
+        N = graph.num_nodes
+        if edge_attr.shape != (graph.num_edges_in, D):
+            raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
+        dev = t4.device
+        out = torch.empty(N, H, dtype=torch.float32, device=dev)
+        alpha = torch.empty(max(graph.num_edges_in, 1), dtype=torch.float32, device=dev)
+        _lib.call("qot_tconv_fwd_graph", t4, 4 * H, M, Pm, w_edge_c, edge_attr, graph.rowptr, maps[1], graph.eid, out, alpha,
+                  n, B, max_e, H, D, *_act_args(act))
+        ctx.save_for_backward(table, wq, wk, wv, ws, w_edge_c, edge_attr, t4, alpha, out if act is not None else None,
+                              act[3] if act is not None else None)
+        ctx.graph, ctx.maps, ctx.plan = graph, maps, plan
+        ctx.act = None if act is None else (act[0], act[1], act[2])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        table, wq, wk, wv, ws, w_edge, edge_attr, t4, alpha, y, act_step = ctx.saved_tensors
+        graph, maps = ctx.graph, ctx.maps
+        n, B, max_e = ctx.plan
+        g = _f32c(g)
+        V, H = table.shape
+        D = w_edge.shape[1]
+        dev = g.device
+        lib = _lib.load()
+        blocks, rowlen = int(lib.qot_tconv_bwd_graph_blocks(B)), int(lib.qot_tconv_graph_row_floats(n, H, D))
+        partials = torch.empty(blocks, rowlen, dtype=torch.float32, device=dev)
+        if ctx.act is not None:
+            slope, p, seed = ctx.act
+            act_args = (y, float(slope), float(p if act_step is not None else 0.0), int(seed), act_step)
+        else:
+            act_args = (None, 0.0, 0.0, 0, None)
+        _lib.call("qot_tconv_bwd_graph", g, *act_args, t4, 4 * H, w_edge, edge_attr, alpha, graph.rowptr, maps[1],
+                  graph.eid, graph.rowptr_t, graph.col_t, graph.pos_t, partials, n, B, max_e, H, D)
+        S = partials[0] if blocks == 1 else torch.empty(rowlen, dtype=torch.float32, device=dev)
+        gt = torch.empty(V * H, dtype=torch.float32, device=dev)
+        gw = torch.empty(4 * H * H, dtype=torch.float32, device=dev)
+        gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        wq_, wk_, wv_, ws_ = (_f32c(t.detach()) for t in (wq, wk, wv, ws))
+        tab = _f32c(table.detach())
+        if LG.enabled():
+            # this node is the last of the pass in table mode: its two jobs ride in the backward epilogue's launches,
+            # which are issued now (everything returned below is filled by them)
+            if blocks > 1:
+                LG.defer(_lib.ROLE_SUM_ROWS, (partials, S), (blocks, rowlen, 0), stage=1)
+            LG.defer(_lib.ROLE_TABLE_PROJECT_BWD_SCORES, (S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb), (V, n, H, D),
+                     stage=2)
+            LG.flush()
+        else:
+            if blocks > 1:
+                wsr = torch.empty(lib.qot_rowsum_wide_workspace_floats(rowlen), dtype=torch.float32, device=dev)
+                _lib.call("qot_rowsum_wide", partials, blocks, rowlen, S, wsr)
+            _lib.call("qot_table_project_bwd_scores", S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb, V, n, H, D)
+        off_gwe = ((2 * n * H + n * ((n + 3) // 4 * 4) + n * D + 3) // 4) * 4         # tg_row(): csrc/tconv_graph_dev.hpp
+        gw2 = gw.view(4 * H, H)
+        return (gt.view(V, H), gw2[:H], gb[:H], gw2[H:2 * H], gb[H:2 * H], gw2[2 * H:3 * H], gb[2 * H:3 * H], gw2[3 * H:],
+                gb[3 * H:], S[off_gwe:off_gwe + H * D].view(H, D), None, None, None, None, None, None)
+
+
 # ------------------------------------------------------------------ NNConv (a4)
 def nnconv_wcat(w2, b2, wroot, hin, hout, k):
     """[(K+2)*Hin, Hout]: K blocks of the edge-MLP's second layer, its bias block, root^T."""

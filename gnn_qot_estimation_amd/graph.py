@@ -35,6 +35,7 @@ class GraphIndex:
     colf: Optional[torch.Tensor] = None     # [E] int32 node_ids[col]
     colf_t: Optional[torch.Tensor] = None   # [E] int32 node_ids[col_t]
     ptr32: Optional[torch.Tensor] = None    # [B+1] int32 graph boundaries
+    sizes: Optional[tuple] = None           # (max nodes, max edges) of one graph: the per-graph build has checked every slice
 
 
 def require_cuda(*tensors):
@@ -129,6 +130,7 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
             # as tensors; it takes the pointers itself while its argument tuple keeps them alive.
             np_c, ep_c = node_ptr.contiguous(), edge_ptr.contiguous()
             status = _index_status(dev)
+            g.sizes = (int(max_n), int(max_m))
             if group is not None and B >= 1:
                 group.add(_lib.ROLE_CSR_BY_GRAPH, (ei, np_c, ep_c, g.rowptr, g.col, g.eid, g.row, g.rowptr_t, g.col_t,
                                                    g.pos_t, g.eid_t, g.invdeg, status, ids, g.ids32, g.colf, g.colf_t,

@@ -69,6 +69,24 @@ class TransformerConv(nn.Module):
             t4 = self.project_table(table, step_pair)
         return QF.TConvFn.apply(t4, edge_attr, self.lin_edge.weight, graph, maps, act)
 
+    def graph_form(self, table, graph: GraphIndex, maps):
+        """``(n, B, max_e)`` when this batch runs in the graph form of table mode (``QF.tconv_graph_plan``), else ``None``."""
+        return QF.tconv_graph_plan(table, self.out_channels, self.edge_dim, graph, maps)
+
+    def prepare_graph_form(self, table, plan, step_pair=None, group=None):
+        """The graph form's table-level inputs ``(t4, M, P)`` from the current parameters; with ``group`` the two jobs join the
+        caller's multi-role launch."""
+        return QF.tconv_graph_prepare(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                      self.lin_key.bias, self.lin_value.weight, self.lin_value.bias, self.lin_skip.weight,
+                                      self.lin_skip.bias, self.lin_edge.weight, plan[0], step_pair, group)
+
+    def forward_table_graph(self, table, edge_attr, graph: GraphIndex, maps, plan, pre, act=None):
+        """``conv(table[node_ids], ...)`` in the graph form: whole graphs per workgroup, the score matrix and the value
+        table in LDS (``csrc/tconv_graph.hip``)."""
+        return QF.TConvGraphFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,
+                                     self.lin_key.bias, self.lin_value.weight, self.lin_value.bias, self.lin_skip.weight,
+                                     self.lin_skip.bias, self.lin_edge.weight, edge_attr, pre, graph, maps, plan, act)
+
     def project_table(self, table, step_pair=None, group=None):
         """``[q|k|v|skip]`` rows of the embedding table, ``[V, 4H]``; with ``group`` the launch is shared."""
         return QF.TableProjectFn.apply(table, self.lin_query.weight, self.lin_query.bias, self.lin_key.weight,

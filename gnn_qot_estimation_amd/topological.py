@@ -158,11 +158,21 @@ class TopologicalGNN(nn.Module):
                 step_pair = (self._qot_step, step)
             else:
                 _lib.call("qot_step_advance", _lib.ptr(self._qot_step), _lib.ptr(step))
-        t4 = self.conv1.project_table(self.node_embeddings.weight, step_pair, grp) if maps is not None else None
+        # table mode: the graph form (whole graphs per workgroup, score matrix in LDS) where the batch allows, else the
+        # per-destination kernels on the projected table
+        plan = self.conv1.graph_form(self.node_embeddings.weight, graph, maps) if maps is not None else None
+        t4 = pre = None
+        if plan is not None:
+            pre = self.conv1.prepare_graph_form(self.node_embeddings.weight, plan, step_pair, grp)
+        elif maps is not None:
+            t4 = self.conv1.project_table(self.node_embeddings.weight, step_pair, grp)
         packed = {layer: getattr(self, f"conv{layer}").prepack(grp) for layer in range(2, self.num_layers + 1)}
         if grp is not None:
             grp.run()
-        if maps is not None:      # x = emb[node_ids]: project the table, gather projected rows
+        if plan is not None:
+            x = self.conv1.forward_table_graph(self.node_embeddings.weight, edge_attr, graph, maps, plan, pre,
+                                               act=self._act(0, step))
+        elif maps is not None:    # x = emb[node_ids]: project the table, gather projected rows
             x = self.conv1.forward_table(self.node_embeddings.weight, edge_attr, graph, maps, act=self._act(0, step),
                                          step_pair=step_pair, t4=t4)
         else:

@@ -635,12 +635,17 @@ def test_dropout_step_agrees_between_execution_modes(cuda_device):
 
 
 @pytest.mark.gpu
-def test_table_mode_without_edge_slices_matches_sliced_batch(cuda_device):
+@pytest.mark.parametrize("graph_form", [False, True])
+def test_table_mode_without_edge_slices_matches_sliced_batch(cuda_device, monkeypatch, graph_form):
     """A batch object that does not carry per-graph edge slices (e.g. a PyG Batch) takes the general index
-    build + qot_table_maps; results must equal the one-launch per-graph build's."""
+    build + qot_table_maps; results must equal the one-launch per-graph build's -- bit for bit when both run the
+    per-destination TransformerConv kernels, to rounding when the sliced batch takes the graph form (r04: it needs the
+    per-graph build's verified slices; the logits' H-term dot is summed in another order there)."""
     import copy
     import gnn_qot_estimation_amd as q
     from gnn_qot_estimation_amd import synthetic as S
+    if not graph_form:
+        monkeypatch.setenv("QOT_NO_TCONV_GRAPH", "1")
     torch.manual_seed(5)
     batch = S.topological_batch(2, 12, n=30, e=100).to(cuda_device)
     plain = batch.to(cuda_device)
@@ -651,10 +656,15 @@ def test_table_mode_without_edge_slices_matches_sliced_batch(cuda_device):
     ya, yb = a(batch), b(plain)
     assert "tmaps" in batch._qot_cache and "tmaps" in plain._qot_cache          # both ran in table mode
     assert batch._qot_cache[("graph", False)][1].colf is not None and plain._qot_cache[("graph", False)][1].colf is None
-    assert torch.equal(ya, yb)
+    same = torch.equal if not graph_form else (lambda u, v: float((u - v).abs().max()) <= 2e-5 * max(float(v.abs().max()), 1e-3))
+    assert same(ya, yb)
     ya.sum().backward(); yb.sum().backward()
-    for pa, pb in zip(a.parameters(), b.parameters()):
-        assert torch.equal(pa.grad, pb.grad)
+    gmax = max(float(pb.grad.abs().max()) for pb in b.parameters())
+    for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+        if graph_form:       # (lin_key.bias: analytically zero, rounding noise on both sides)
+            assert float((pa.grad - pb.grad).abs().max()) <= 2e-5 * max(float(pb.grad.abs().max()), 1e-3 * gmax, gmax if name == "conv1.lin_key.bias" else 0.0), name
+        else:
+            assert torch.equal(pa.grad, pb.grad), name
 
 
 @pytest.mark.gpu
@@ -1135,6 +1145,7 @@ def test_tile_form_forward_is_taken_only_for_small_graphs(cuda_device, monkeypat
     calls = []
     real = _lib.call
     monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    monkeypatch.setenv("QOT_NO_TCONV_GRAPH", "1")       # r04: graphs of <= 128 nodes take the graph form first (test_gpu_tconv_graph.py)
     for n, e, H, want_tile in ((100, 400, 64, True), (1000, 4000, 128, False), (75, 60, 16, True)):
         calls.clear()
         batch = S.topological_batch(2, 4, n=n, e=e).to(cuda_device)
