@@ -56,11 +56,11 @@ SIGNATURES = {
     "qot_tconv_graph_row_floats": (_sz, [_int, _int, _int]),
     "qot_tconv_bwd_graph_blocks": (_int, [_i64]),
     "qot_table_scores": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _int, _p]),
-    "qot_tconv_fwd_graph": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _int, _int, _int, _f, _f,
-                                   _u64, _p, _p]),
-    "qot_tconv_bwd_graph": (_int, [_p, _p, _f, _f, _u64, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64,
-                                   _int, _int, _int, _p]),
-    "qot_table_project_bwd_scores": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _int, _int, _p]),
+    "qot_tconv_fwd_graph": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _int, _int,
+                                   _int, _f, _f, _u64, _p, _p]),
+    "qot_tconv_bwd_graph": (_int, [_p, _p, _f, _f, _u64, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int,
+                                   _i64, _int, _int, _int, _p]),
+    "qot_table_project_bwd_scores": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _int, _int, _int, _p]),
     "qot_nnconv_agg": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p, _i64, _int, _int, _p]),
     "qot_nnconv_fused": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _i64, _int, _int,
                                 _int, _f, _f, _u64, _p, _p]),

@@ -160,6 +160,22 @@ __device__ __forceinline__ float4 act_apply4(float4 v, const ActParams& a, uint6
     return make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// as act_apply4 with the step counter's value already in a register (kernels that apply the epilogue many times per
+// thread read the counter once: a load per use is a global round trip in front of every store)
+__device__ __forceinline__ float4 act_apply4s(float4 v, const ActParams& a, uint64_t step, uint64_t idx4) {
+    if (!a.enabled) return v;
+    float r[4] = {v.x, v.y, v.z, v.w};
+    uint64_t z = 0;
+    if (a.thr16) z = act_hash64(a.seed, step, idx4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float y = r[c] > 0.f ? r[c] : a.slope * r[c];
+        if (a.thr16) y = (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= a.thr16) ? y * a.keep_scale : 0.f;
+        r[c] = y;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 inline ActParams make_act(int act, float slope, float p, uint64_t seed, const int64_t* step) {
     ActParams a;
     a.enabled = act; a.slope = slope; a.thr16 = 0; a.keep_scale = 1.0f; a.seed = seed; a.step = step;

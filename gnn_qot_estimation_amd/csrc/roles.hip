@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void roles_kernel(const RoleTable t_by_value) 
         QOT_ROLE_H((int)ro.i[2], table_project_bwd_scores_body<kH>(rp<const float>(ro, 0), rp<const float>(ro, 1),
                                                                    rp<const float>(ro, 2), rp<const float>(ro, 3), p,
                                                                    rp<float>(ro, 8), rp<float>(ro, 9), rp<float>(ro, 10),
-                                                                   (int)ro.i[0], (int)ro.i[1], (int)ro.i[3], vb,
+                                                                   rp<float>(ro, 11), (int)ro.i[0], (int)ro.i[1], (int)ro.i[3], vb,
                                                                    reinterpret_cast<float*>(dyn_lds)));
         break;
     }
@@ -235,9 +235,10 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
         const int64_t V = i[0], n = i[1], H = i[2], D = i[3];
         if (V <= 0 || n <= 0 || n > V || D <= 0) return QOT_ERR_BADARG;
         if (!width_ok(H) || D > 8 || table_rows_per_block(V) > 1) return QOT_ERR_UNSUPPORTED;
-        for (int k = 0; k < 11; ++k) if (!p[k]) return QOT_ERR_BADARG;
-        *blocks = 4 * H + V;
-        *lds = (size_t)(512 + (4 * H > n ? 4 * H : n)) * 4;
+        if (n > kTgMaxN) return QOT_ERR_UNSUPPORTED;
+        for (int k = 0; k < 12; ++k) if (!p[k]) return QOT_ERR_BADARG;
+        *blocks = 4 * H + V + 1;
+        *lds = (size_t)tg_bwd_scores_lds_floats((int)n, (int)H, (int)D) * 4;
         return QOT_OK;
     }
     default:

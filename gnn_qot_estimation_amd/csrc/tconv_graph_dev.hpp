@@ -37,7 +37,7 @@ __host__ __device__ inline TgRow tg_row(int n, int H, int D) {
 }
 
 constexpr int kTgMaxN = 128;             // nodes per graph the graph form takes (register-resident accumulators, LDS)
-constexpr int kScoreRows = 8;            // query rows per workgroup of table_scores_body
+constexpr int kScoreRows = 4;            // query rows per workgroup of table_scores_body (latency-bound: many small workgroups)
 
 // ---- M [n, ldm] and P [n, D] from the PARAMETERS (no dependence on the projected table: the job shares the forward
 // prologue's launch with the projection itself).  With u_r = Wk^T T_q[r] and beta_r = <T_q[r], bk>:
@@ -67,8 +67,8 @@ __device__ __forceinline__ void table_scores_body(const float* __restrict__ tabl
         const int r = c / H, o = c % H;
         const float* w = wq + (int64_t)o * H;
         float acc = bq[o];
-#pragma unroll 4
-        for (int a = 0; a < H; a += 4) {
+#pragma unroll 8
+        for (int a = 0; a < H; a += 4) {          // (eight loads in flight: the job is a chain of L2 round trips otherwise)
             const float4 ww = ld4(w + a);
             const float4 xv = *reinterpret_cast<const float4*>(er + r * H + a);
             acc = fmaf(ww.x, xv.x, acc); acc = fmaf(ww.y, xv.y, acc);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void table_scores_body(const float* __restrict__ tabl
         if (j < n) {
             const float* ej = table + (int64_t)j * H;
             acc = beta[r];
-#pragma unroll 4
+#pragma unroll 8
             for (int a = 0; a < H; a += 4) {
                 const float4 ev = ld4(ej + a);
                 const float4 uv = *reinterpret_cast<const float4*>(u + r * H + a);
@@ -121,116 +121,176 @@ __device__ __forceinline__ void table_scores_body(const float* __restrict__ tabl
 // q / k columns of the table gradient formed where they are needed.  t4 = the projected table [V, 4H] (T_q | T_k | ...).
 //   weight part, one workgroup per packed column c:  gcol[v] (v < n, 0 above) -> gw[c, :] = sum_v gcol[v] table[v, :], gb[c]
 //   table part, one workgroup per table row v:       grow[4H] -> gt[v, :] = sum_c grow[c] w_{s(c)}[o(c), :]
-// `lds`: 512 + max(4H, n) floats.
-template <int H>
-__device__ __forceinline__ float tg_gp_entry(const float* __restrict__ S, const TgRow& L, const float* __restrict__ t4,
-                                             const float* __restrict__ we, int n, int D, int v, int c, float rs) {
-    if (v >= n) return 0.f;
-    const int s = c / H, o = c % H;
-    if (s == 2) return S[L.off_gv + v * H + o];
-    if (s == 3) return S[L.off_gs + v * H + o];
+//   one more workgroup: grad w_edge [H, D] = S's value-path share + T_q^T gP / sqrt(H)
+// The jobs are chains of L2 round trips (a trip costs ~0.7 us next to the other jobs of the launch), so every loop requests a
+// batch of independent loads before its first product, and the inner sums are split over thread halves that meet in LDS in a
+// fixed order.  n <= kTgMaxN (= 128: two threads per row in the gradient-slice sums).
+// `lds`: tg_bwd_scores_lds_floats(n, H, D) floats.
+__host__ __device__ inline int tg_bwd_scores_lds_floats(int n, int H, int D) {
+    const int a = 512 + (4 * H > kTgMaxN ? 4 * H : kTgMaxN) + 2 * kTgMaxN;     // red | redb | gradient slice (a column of up to
+                                                                              // kTgMaxN rows, or a row of 4H) | halves
+    const int b = n * H + pad4(n * D);                       // the w_edge job: T_q, gP
+    return a > b ? a : b;
+}
+
+// sum_{k in [k0, k1)} x[k * xs] * y[k * ys]: eight terms' operands requested before the first product
+__device__ __forceinline__ float tg_strided_dot(const float* __restrict__ x, int64_t xs, const float* __restrict__ y, int64_t ys,
+                                                int k0, int k1) {
+    constexpr int U = 8;
     float acc = 0.f;
-    // (eight terms' operands requested before the first product: a load -> use chain per trip serialises the round trips)
-    if (s == 0) {            // rs (sum_j gM[v][j] T_k[j][o] + sum_d gP[v][d] We[o][d])
-        const float* gm = S + L.off_gm + (int64_t)v * L.ldm;
-        const float* tk = t4 + H + o;
-        int j = 0;
-        for (; j + 8 <= n; j += 8) {
-            const float4 ga = ld4(gm + j), gb4 = ld4(gm + j + 4);
-            float k[8];
+    for (int k = k0; k < k1; k += U) {
+        float a[U], b[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) k[u] = tk[(int64_t)(j + u) * 4 * H];
-            acc = fmaf(ga.x, k[0], acc); acc = fmaf(ga.y, k[1], acc); acc = fmaf(ga.z, k[2], acc); acc = fmaf(ga.w, k[3], acc);
-            acc = fmaf(gb4.x, k[4], acc); acc = fmaf(gb4.y, k[5], acc); acc = fmaf(gb4.z, k[6], acc); acc = fmaf(gb4.w, k[7], acc);
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + u < k1 ? k + u : k0;
+            a[u] = x[(int64_t)kk * xs]; b[u] = y[(int64_t)kk * ys];
         }
-        for (; j < n; ++j) acc = fmaf(gm[j], tk[(int64_t)j * 4 * H], acc);
-        for (int d = 0; d < D; ++d) acc = fmaf(S[L.off_gp + v * D + d], we[o * D + d], acc);
-    } else {                 // rs sum_r gM[r][v] T_q[r][o]
-        const float* gm = S + L.off_gm + v;
-        const float* tq = t4 + o;
-        int r = 0;
-        for (; r + 8 <= n; r += 8) {
-            float g[8], q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                g[u] = gm[(int64_t)(r + u) * L.ldm];
-                q[u] = tq[(int64_t)(r + u) * 4 * H];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(g[u], q[u], acc);
-        }
-        for (; r < n; ++r) acc = fmaf(gm[(int64_t)r * L.ldm], tq[(int64_t)r * 4 * H], acc);
+        for (int u = 0; u < U; ++u) acc = fmaf(k + u < k1 ? a[u] : 0.f, b[u], acc);
     }
-    return acc * rs;
+    return acc;
 }
 
 template <int H>
 __device__ __forceinline__ void table_project_bwd_scores_body(const float* __restrict__ S, const float* __restrict__ t4,
                                                               const float* __restrict__ we, const float* __restrict__ table,
                                                               const Proj4& p, float* __restrict__ gtable,
-                                                              float* __restrict__ gw, float* __restrict__ gb, int V, int n,
-                                                              int D, int vb, float* __restrict__ lds) {
+                                                              float* __restrict__ gw, float* __restrict__ gb,
+                                                              float* __restrict__ gwe, int V, int n, int D, int vb,
+                                                              float* __restrict__ lds) {
     constexpr int PH = (H >= 256) ? 1 : 256 / H;
     const TgRow L = tg_row(n, H, D);
     const float rs = rsqrtf((float)H);
     float* red = lds;                  // [256]
     float* redb = lds + 256;           // [256]
     float* gs = lds + 512;             // the gradient slice: column (n) or row (4H)
+    float* half = gs + (4 * H > kTgMaxN ? 4 * H : kTgMaxN);      // [2][kTgMaxN] halves of a column sum
     const int a = threadIdx.x % H, ph = threadIdx.x / H;
+    const float* gM = S + L.off_gm;
     if (vb < 4 * H) {
-        const int c = vb;
-        for (int v = threadIdx.x; v < n; v += 256) gs[v] = tg_gp_entry<H>(S, L, t4, we, n, D, v, c, rs);
+        // ---- weight part, packed column c
+        const int c = vb, s = c / H, o = c % H;
+        const int v = threadIdx.x % kTgMaxN, hf = threadIdx.x / kTgMaxN;          // two threads per row v
+        const int mid = pad4((n + 1) / 2);
+        const int k0 = hf == 0 ? 0 : (mid < n ? mid : n), k1 = hf == 0 ? (mid < n ? mid : n) : n;
+        float part = 0.f;
+        if (v < n) {
+            if (s == 0) part = tg_strided_dot(gM + (int64_t)v * L.ldm, 1, t4 + H + o, 4 * H, k0, k1);        // sum_j gM[v][j] T_k[j][o]
+            else if (s == 1) part = tg_strided_dot(gM + v, L.ldm, t4 + o, 4 * H, k0, k1);                    // sum_r gM[r][v] T_q[r][o]
+            else if (hf == 0) part = S[(s == 2 ? L.off_gv : L.off_gs) + v * H + o];
+        }
+        half[hf * kTgMaxN + v] = part;
+        __syncthreads();
+        if (threadIdx.x < kTgMaxN) {
+            float g = 0.f;
+            if (v < n) {
+                g = half[v] + half[kTgMaxN + v];
+                if (s == 0) {
+                    for (int d = 0; d < D; ++d) g = fmaf(S[L.off_gp + v * D + d], we[o * D + d], g);
+                }
+                if (s < 2) g *= rs;
+            }
+            gs[v] = g;
+        }
         __syncthreads();
         float acc = 0.f, sb = 0.f;
-        int v = ph;
-        for (; v + 7 * PH < n; v += 8 * PH) {
+        int vv = ph;
+        for (; vv + 7 * PH < n; vv += 8 * PH) {
             float tv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tv[u] = table[(int64_t)(v + u * PH) * H + a];
+            for (int u = 0; u < 8; ++u) tv[u] = table[(int64_t)(vv + u * PH) * H + a];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const float gv = gs[v + u * PH]; acc = fmaf(gv, tv[u], acc); sb += gv; }
+            for (int u = 0; u < 8; ++u) { const float gv = gs[vv + u * PH]; acc = fmaf(gv, tv[u], acc); sb += gv; }
         }
-        for (; v < n; v += PH) {
-            const float gv = gs[v];
-            acc = fmaf(gv, table[(int64_t)v * H + a], acc);
+        for (; vv < n; vv += PH) {
+            const float gv = gs[vv];
+            acc = fmaf(gv, table[(int64_t)vv * H + a], acc);
             sb += gv;
         }
         red[threadIdx.x] = acc;
         redb[threadIdx.x] = sb;
         __syncthreads();
         if (ph == 0) {
-            float s = acc, t = sb;
-            for (int k = 1; k < PH; ++k) { s += red[k * H + a]; t += redb[k * H + a]; }
-            gw[(int64_t)c * H + a] = s;
+            float sa = acc, t = sb;
+            for (int k = 1; k < PH; ++k) { sa += red[k * H + a]; t += redb[k * H + a]; }
+            gw[(int64_t)c * H + a] = sa;
             if (a == 0) gb[c] = t;
         }
-    } else {
+    } else if (vb < 4 * H + V) {
+        // ---- table part, row v
         const int v = vb - 4 * H;
-        for (int c = threadIdx.x; c < 4 * H; c += 256) gs[c] = tg_gp_entry<H>(S, L, t4, we, n, D, v, c, rs);
+        if (v >= n) {                  // rows no node refers to: zero gradient
+            if (ph == 0) gtable[(int64_t)v * H + a] = 0.f;
+            return;
+        }
+        // the row of the gradient: thread (o, ph) sums a share of the inner index for the q and the k column o
+        {
+            const int per = (n + PH - 1) / PH;
+            const int k0 = ph * per < n ? ph * per : n, k1 = (ph + 1) * per < n ? (ph + 1) * per : n;
+            const float pq = tg_strided_dot(gM + (int64_t)v * L.ldm, 1, t4 + H + a, 4 * H, k0, k1);
+            const float pk = tg_strided_dot(gM + v, L.ldm, t4 + a, 4 * H, k0, k1);
+            red[threadIdx.x] = pq;
+            redb[threadIdx.x] = pk;
+        }
+        __syncthreads();
+        if (ph == 0) {
+            float q = red[a], k = redb[a];
+            for (int u = 1; u < PH; ++u) { q += red[u * H + a]; k += redb[u * H + a]; }
+            for (int d = 0; d < D; ++d) q = fmaf(S[L.off_gp + v * D + d], we[a * D + d], q);
+            gs[a] = q * rs;
+            gs[H + a] = k * rs;
+            gs[2 * H + a] = S[L.off_gv + v * H + a];
+            gs[3 * H + a] = S[L.off_gs + v * H + a];
+        }
         __syncthreads();
         float acc = 0.f;
-        if (v < n) {                   // rows no node refers to: zero gradient
-            for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {
-                float wv[8];
+        for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {              // 4H / PH trips: a multiple of 8 for every width
+            float wv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + u * PH;
-                    const int cc = c < 4 * H ? c : ph;
-                    wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * PH;
+                const int cc = c < 4 * H ? c : ph;
+                wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + u * PH;
-                    if (c < 4 * H) acc = fmaf(gs[c], wv[u], acc);
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * PH;
+                if (c < 4 * H) acc = fmaf(gs[c], wv[u], acc);
             }
         }
+        __syncthreads();
         red[threadIdx.x] = acc;
         __syncthreads();
         if (ph == 0) {
-            float s = acc;
-            for (int k = 1; k < PH; ++k) s += red[k * H + a];
-            if (v < V) gtable[(int64_t)v * H + a] = s;
+            float sa = acc;
+            for (int k = 1; k < PH; ++k) sa += red[k * H + a];
+            gtable[(int64_t)v * H + a] = sa;
+        }
+    } else {
+        // ---- grad w_edge: value path (already summed in S) + T_q^T gP / sqrt(H); T_q and gP staged in LDS
+        float* tq = lds;                       // [n][H]
+        float* gp = lds + n * H;               // [n][D]
+        for (int i0 = threadIdx.x; i0 < n * H; i0 += 8 * 256) {
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int ii = i < n * H ? i : 0;
+                q[u] = t4[(int64_t)(ii / H) * 4 * H + ii % H];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < n * H) tq[i] = q[u];
+            }
+        }
+        for (int i = threadIdx.x; i < n * D; i += 256) gp[i] = S[L.off_gp + i];
+        __syncthreads();
+        for (int o = threadIdx.x; o < H * D; o += 256) {
+            const int c = o / D, d = o % D;
+            float acc = 0.f;
+            for (int r = 0; r < n; ++r) acc = fmaf(tq[r * H + c], gp[r * D + d], acc);
+            gwe[o] = fmaf(rs, acc, S[L.off_gwe + o]);
         }
     }
 }

@@ -429,10 +429,14 @@ class TConvGraphFn(torch.autograd.Function):
             raise ValueError(f"edge_attr must be [{graph.num_edges_in}, {D}], got {tuple(edge_attr.shape)}")
         dev = t4.device
         out = torch.empty(N, H, dtype=torch.float32, device=dev)
-        alpha = torch.empty(max(graph.num_edges_in, 1), dtype=torch.float32, device=dev)
-        _lib.call("qot_tconv_fwd_graph", t4, 4 * H, M, Pm, w_edge_c, edge_attr, graph.rowptr, maps[1], graph.eid, out, alpha,
-                  n, B, max_e, H, D, *_act_args(act))
-        ctx.save_for_backward(table, wq, wk, wv, ws, w_edge_c, edge_attr, t4, alpha, out if act is not None else None,
+        E = max(graph.num_edges_in, 1)
+        # left behind for the backward: attention weights and edge features in CSR slot order, sum alpha ea per node
+        alpha = torch.empty(E, dtype=torch.float32, device=dev)
+        ea_csr = torch.empty(E, D, dtype=torch.float32, device=dev)
+        aa = torch.empty(max(N, 1), D, dtype=torch.float32, device=dev)
+        _lib.call("qot_tconv_fwd_graph", t4, 4 * H, M, Pm, w_edge_c, edge_attr, graph.rowptr, maps[1], graph.eid, graph.row,
+                  out, alpha, ea_csr, aa, n, B, max_e, H, D, *_act_args(act))
+        ctx.save_for_backward(table, wq, wk, wv, ws, w_edge_c, t4, alpha, ea_csr, aa, out if act is not None else None,
                               act[3] if act is not None else None)
         ctx.graph, ctx.maps, ctx.plan = graph, maps, plan
         ctx.act = None if act is None else (act[0], act[1], act[2])
@@ -440,7 +444,7 @@ class TConvGraphFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        table, wq, wk, wv, ws, w_edge, edge_attr, t4, alpha, y, act_step = ctx.saved_tensors
+        table, wq, wk, wv, ws, w_edge, t4, alpha, ea_csr, aa, y, act_step = ctx.saved_tensors
         graph, maps = ctx.graph, ctx.maps
         n, B, max_e = ctx.plan
         g = _f32c(g)
@@ -455,12 +459,13 @@ class TConvGraphFn(torch.autograd.Function):
             act_args = (y, float(slope), float(p if act_step is not None else 0.0), int(seed), act_step)
         else:
             act_args = (None, 0.0, 0.0, 0, None)
-        _lib.call("qot_tconv_bwd_graph", g, *act_args, t4, 4 * H, w_edge, edge_attr, alpha, graph.rowptr, maps[1],
-                  graph.eid, graph.rowptr_t, graph.col_t, graph.pos_t, partials, n, B, max_e, H, D)
+        _lib.call("qot_tconv_bwd_graph", g, *act_args, t4, 4 * H, w_edge, ea_csr, alpha, aa, graph.rowptr, maps[1],
+                  graph.row, graph.rowptr_t, graph.col_t, graph.pos_t, partials, n, B, max_e, H, D)
         S = partials[0] if blocks == 1 else torch.empty(rowlen, dtype=torch.float32, device=dev)
         gt = torch.empty(V * H, dtype=torch.float32, device=dev)
         gw = torch.empty(4 * H * H, dtype=torch.float32, device=dev)
         gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
+        gwe = torch.empty(H, D, dtype=torch.float32, device=dev)
         wq_, wk_, wv_, ws_ = (_f32c(t.detach()) for t in (wq, wk, wv, ws))
         tab = _f32c(table.detach())
         if LG.enabled():
@@ -468,18 +473,17 @@ class TConvGraphFn(torch.autograd.Function):
             # which are issued now (everything returned below is filled by them)
             if blocks > 1:
                 LG.defer(_lib.ROLE_SUM_ROWS, (partials, S), (blocks, rowlen, 0), stage=1)
-            LG.defer(_lib.ROLE_TABLE_PROJECT_BWD_SCORES, (S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb), (V, n, H, D),
-                     stage=2)
+            LG.defer(_lib.ROLE_TABLE_PROJECT_BWD_SCORES, (S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb, gwe),
+                     (V, n, H, D), stage=2)
             LG.flush()
         else:
             if blocks > 1:
                 wsr = torch.empty(lib.qot_rowsum_wide_workspace_floats(rowlen), dtype=torch.float32, device=dev)
                 _lib.call("qot_rowsum_wide", partials, blocks, rowlen, S, wsr)
-            _lib.call("qot_table_project_bwd_scores", S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb, V, n, H, D)
-        off_gwe = ((2 * n * H + n * ((n + 3) // 4 * 4) + n * D + 3) // 4) * 4         # tg_row(): csrc/tconv_graph_dev.hpp
+            _lib.call("qot_table_project_bwd_scores", S, t4, w_edge, tab, wq_, wk_, wv_, ws_, gt, gw, gb, gwe, V, n, H, D)
         gw2 = gw.view(4 * H, H)
         return (gt.view(V, H), gw2[:H], gb[:H], gw2[H:2 * H], gb[H:2 * H], gw2[2 * H:3 * H], gb[2 * H:3 * H], gw2[3 * H:],
-                gb[3 * H:], S[off_gwe:off_gwe + H * D].view(H, D), None, None, None, None, None, None)
+                gb[3 * H:], gwe, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------ NNConv (a4)

@@ -183,15 +183,17 @@ int qot_tconv_bwd_src(const float* grad_out, int ld_go, const float* q, int ld, 
  * block-diagonal batch) with M and T_v in LDS.  colf = node_ids[col] (= the source's index inside its graph).
  * qot_tconv_graph_supported(n, max_e, H, D): n <= 128 and the LDS images fit (max_e = most edges of one graph);
  * the entry points return QOT_ERR_UNSUPPORTED otherwise and callers use qot_tconv_fwd / qot_tconv_bwd_*.
- * fwd: out [N,H] as qot_tconv_fwd (same fused activation, same dropout mask), alpha [E] = the attention weights in
- * CSR slot order, kept for the backward (it needs no logits).
+ * fwd: out [N,H] as qot_tconv_fwd (same fused activation, same dropout mask); row = the index's destination of every
+ * CSR slot.  Left behind for the backward (it needs no logits): alpha [E] = the attention weights, ea_csr [E,D] = the
+ * edge features, both in CSR slot order, and aa [N,D] = sum_e alpha_e ea_e per destination.
  * bwd: grad_out [N,H] (through the fused activation when y_act != NULL, as qot_tconv_bwd_dst) ->
  * partials [qot_tconv_bwd_graph_blocks(B)][qot_tconv_graph_row_floats(n,H,D)], one row per workgroup:
- *     [ grad T_v n*H | grad T_skip n*H | grad M n*ldm | grad P n*D | grad w_edge H*D ]   (each part padded to 4 floats)
- * The caller sums the rows in order (QOT_ROLE_SUM_ROWS: bitwise reproducible); grad w_edge of the summed row is final.
+ *     [ grad T_v n*H | grad T_skip n*H | grad M n*ldm | grad P n*D | grad w_edge (value path) H*D ]   (parts padded to 4 floats)
+ * The caller sums the rows in order (QOT_ROLE_SUM_ROWS: bitwise reproducible).
  * qot_table_project_bwd_scores is qot_table_project_bwd fed by that summed row S: it forms
  *     grad T_q = (grad M T_k + grad P w_edge^T) / sqrt(H),   grad T_k = grad M^T T_q / sqrt(H)
- * where it needs them (rows >= n of the table receive zero) -- the [V, 4H] table gradient is never materialised. */
+ * where it needs them (rows >= n of the table receive zero) -- the [V, 4H] table gradient is never materialised -- and
+ * completes grad w_edge [H,D] = S's value-path share + T_q^T grad P / sqrt(H). */
 int qot_tconv_graph_supported(int n, int max_e, int H, int D);
 int qot_tconv_graph_ldm(int n);
 size_t qot_tconv_graph_row_floats(int n, int H, int D);
@@ -200,16 +202,18 @@ int qot_table_scores(const float* table, const float* wq, const float* bq, const
                      const float* w_edge, float* M, float* P, int n, int H, int D, qot_stream_t stream);
 int qot_tconv_fwd_graph(const float* t4, int ld, const float* M, const float* P, const float* w_edge,
                         const float* edge_attr, const int32_t* rowptr, const int32_t* colf, const int32_t* eid,
-                        float* out, float* alpha, int n, int64_t B, int max_e, int H, int D, int act, float act_slope,
-                        float act_p, uint64_t act_seed, const int64_t* act_step, qot_stream_t stream);
+                        const int32_t* row, float* out, float* alpha, float* ea_csr, float* aa, int n, int64_t B, int max_e,
+                        int H, int D, int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
+                        qot_stream_t stream);
 int qot_tconv_bwd_graph(const float* grad_out, const float* y_act, float act_slope, float act_p, uint64_t act_seed,
-                        const int64_t* act_step, const float* t4, int ld, const float* w_edge, const float* edge_attr,
-                        const float* alpha, const int32_t* rowptr, const int32_t* colf, const int32_t* eid,
-                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t, float* partials, int n,
-                        int64_t B, int max_e, int H, int D, qot_stream_t stream);
+                        const int64_t* act_step, const float* t4, int ld, const float* w_edge, const float* ea_csr,
+                        const float* alpha, const float* aa, const int32_t* rowptr, const int32_t* colf,
+                        const int32_t* row, const int32_t* rowptr_t, const int32_t* col_t, const int32_t* pos_t,
+                        float* partials, int n, int64_t B, int max_e, int H, int D, qot_stream_t stream);
 int qot_table_project_bwd_scores(const float* S, const float* t4, const float* w_edge, const float* table,
                                  const float* wq, const float* wk, const float* wv, const float* ws, float* grad_table,
-                                 float* grad_w, float* grad_b, int V, int n, int H, int D, qot_stream_t stream);
+                                 float* grad_w, float* grad_b, float* grad_w_edge, int V, int n, int H, int D,
+                                 qot_stream_t stream);
 
 /* ---- NNConv (aggr = mean), factorised ----------------------------------------------
  * h_e = relu(W1 ea_e + b1) in R^K, K = 2D.  Builds the GEMM operand
@@ -544,7 +548,7 @@ int qot_skinny_linear_dw(const float* g, const float* x, float* partials, int64_
  * QOT_ROLE_TABLE_SCORES       0 table, 1 wq, 2 bq, 3 wk, 4 bk, 5 w_edge, 6 M, 7 P          0 n, 1 H, 2 D
  *                             (as qot_table_scores)
  * QOT_ROLE_TABLE_PROJECT_BWD_SCORES  0 S, 1 t4, 2 w_edge, 3 table, 4 wq, 5 wk, 6 wv, 7 ws,  0 V, 1 n, 2 H, 3 D
- *                             8 grad_table, 9 grad_w, 10 grad_b (as qot_table_project_bwd_scores)
+ *                             8 grad_table, 9 grad_w, 10 grad_b, 11 grad_w_edge (as qot_table_project_bwd_scores)
  * "derived" fields are filled by the library in its own copy; callers leave them 0. */
 #define QOT_MAX_ROLES 12
 enum {
