@@ -192,9 +192,17 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False, group=No
     ids = getattr(data, "node_ids", None) if (slices is not None and getattr(data, "uniform_node_ids", None)) else None
     g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids, group=group)
     if c is not None:
-        c[key] = (tag, g)
-        if g.ptr32 is not None:       # read-out boundaries came with the index
-            c["ptr32"] = ((ptr.data_ptr(), ptr._version, tuple(ptr.shape)), (g.ptr32, ptr.numel() - 1))
+        def remember():
+            c[key] = (tag, g)
+            if g.ptr32 is not None:       # read-out boundaries came with the index
+                c["ptr32"] = ((ptr.data_ptr(), ptr._version, tuple(ptr.shape)), (g.ptr32, ptr.numel() - 1))
+        if group is not None and group.roles:
+            # the build is still WAITING in the caller's multi-role launch: the index enters the cache only after that
+            # launch has run and its status read-back has passed -- a batch with inconsistent slices (QotError) or a forward
+            # that raises before the launch must not leave torch.empty arrays behind for the next forward to gather through
+            group.on_success.append(remember)
+        else:
+            remember()
     return g
 
 
@@ -316,7 +324,10 @@ def table_maps_for(data, graph: GraphIndex, group=None):
     if graph.colf is not None and graph.ids32 is not None:      # built together with the index
         res = (graph.ids32, graph.colf, graph.colf_t, (N // n, int(n)))
         if c is not None:
-            c["tmaps"] = (tag, res)
+            if group is not None and group.roles:              # as the index itself: cached once the launch went through
+                group.on_success.append(lambda: c.__setitem__("tmaps", (tag, res)))
+            else:
+                c["tmaps"] = (tag, res)
         return res
     require_cuda(ids)
     if group is not None and group.roles:

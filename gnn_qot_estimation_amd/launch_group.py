@@ -16,6 +16,13 @@ Two users:
   still takes them without a copy.
 
 ``QOT_NO_LAUNCH_GROUPS=1`` restores one launch per job (A/B measurements, bisecting).
+
+Threading: the backward queue is ONE module-level object armed through an autograd-engine callback -- right for the
+single-threaded step the reference runs (``topological_training/train.py:107-116``), NOT for two backward passes in flight
+on different host threads (their jobs would share a queue and a stream).  Such callers set ``QOT_NO_LAUNCH_GROUPS=1``
+("Threads").  A deferred gradient is only handed out when nothing can read it before the flush:
+``can_defer`` refuses receivers with an existing ``.grad``, tensor hooks, post-accumulate hooks, a non-contiguous layout, or
+one Parameter appearing twice.
 """
 from __future__ import annotations
 
@@ -43,6 +50,14 @@ def can_defer(*receivers) -> bool:
             continue
         if not isinstance(t, torch.Tensor) or not t.is_leaf or t.grad is not None:
             return False
+        # a tensor hook / post-accumulate-grad hook runs on the gradient AT ONCE (on the still unfilled buffer), and a
+        # receiver that is not contiguous makes AccumulateGrad clone the buffer at once (gradient layout contract)
+        if getattr(t, "_backward_hooks", None) or getattr(t, "_post_accumulate_grad_hooks", None) or not t.is_contiguous():
+            return False
+    # one Parameter used by two nodes (tied weights): the engine's InputBuffer ADDS the two gradients as they arrive
+    ids = [id(t) for t in receivers if t is not None]
+    if len(ids) != len(set(ids)):
+        return False
     return not torch.is_grad_enabled()   # create_graph=True: AccumulateGrad clones what it is given
 
 
@@ -51,6 +66,7 @@ class LaunchGroup:
 
     def __init__(self):
         self.roles, self.keep, self.post = [], [], []
+        self.on_success = []         # run after the launch AND the post checks went through (e.g. cache insertions)
 
     def add(self, kind: int, ptrs, ints, keep=()):
         self.roles.append(_lib.make_role(kind, ptrs, ints))
@@ -58,13 +74,15 @@ class LaunchGroup:
         self.keep.extend(keep)
 
     def run(self):
-        roles, post = self.roles, self.post
-        self.roles, self.post = [], []
+        roles, post, done = self.roles, self.post, self.on_success
+        self.roles, self.post, self.on_success = [], [], []
         try:
             _lib.run_roles(roles)
         finally:
             self.keep = []
         for fn in post:
+            fn()                     # may raise (status read-back): nothing below runs then
+        for fn in done:
             fn()
 
 

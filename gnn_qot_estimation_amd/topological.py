@@ -200,7 +200,9 @@ class TopologicalGNN(nn.Module):
             if loss_spec is not None and torch.is_grad_enabled():
                 target, beta, loss_out = loss_spec
                 if loss_out is None:
-                    loss_out = torch.empty((), dtype=torch.float32, device=x.device)
+                    # filled by the backward epilogue: NaN until then (a caller that reads it before / without backward()
+                    # must not see uninitialised memory)
+                    loss_out = torch.full((), float("nan"), dtype=torch.float32, device=x.device)
                 out, gout = QF.HeadFn.apply(x, ptr, l0.weight, l0.bias, l3.weight, l3.bias, B, act,
                                             last_act if side is not None else None, side, (target, beta, loss_out, True))
                 return out, gout, loss_out
