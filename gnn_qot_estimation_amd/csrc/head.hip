@@ -255,16 +255,71 @@ __global__ __launch_bounds__(256) void head_train_kernel(
         for (int e = 0; e < PER; ++e) w0s[((t + 256 * e) / H) * HP + (t + 256 * e) % H] = wv[e];
     }
     for (int e = t; e < O * H; e += 256) w3s[e] = w3[e];
+    // per-thread constants of the graph loop, read ONCE (a load per use is a global round trip inside a chain of eight
+    // barrier-separated phases per graph: the step counters alone were one trip per node row of the pool backward)
+    const uint64_t stepv = act.thr16 ? (uint64_t)act.step[0] : 0;
+    const uint64_t in_stepv = (fold && in_act.thr16) ? (uint64_t)in_act.step[0] : 0;
+    const float b0t = t < H ? b0[t] : 0.f;
+    const float b3t = t < O ? b3[t] : 0.f;
+    // The NEXT graph's first rows (and its target) are requested before the current graph's phases, its boundaries one graph
+    // earlier still: a graph then costs no exposed round trip of its own (first version: boundaries -> rows -> eight phases,
+    // back to back, per graph)
+    int vz = 0;
+    asm volatile("" : "+v"(vz));                 // boundaries through VECTOR loads (a scalar load shares lgkmcnt with LDS)
+    int pbeg = 0, pend = 0, nbeg = 0, nend = 0;
+    float4 pv[8];
+    float ptgt = 0.f;
+    {
+        const int64_t b = blockIdx.x;
+        if (b < B) { pbeg = ptr[b + vz]; pend = ptr[b + 1 + vz]; }
+        const int64_t bn = b + gridDim.x;
+        if (bn < B) { nbeg = ptr[bn + vz]; nend = ptr[bn + 1 + vz]; }
+        const int pc = pend - pbeg;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = slot + u * RPB;
+            pv[u] = (slot < RPB && pc > 0) ? ld4(x + (int64_t)(pbeg + (r < pc ? r : 0)) * H + 4 * sub) : f4zero();   // (an empty graph owns no row)
+        }
+        if (t < O && b < B) ptgt = target[b * O + t];
+    }
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const int beg = ptr[b], end = ptr[b + 1];
+        const int beg = pbeg, end = pend;
         const int cnt = end - beg;
         const bool in_lds = cnt <= kHeadRowsCap;
+        const float tgt = ptgt;
+        float4 v0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v0[u] = pv[u];
+        {   // request the next graph
+            const int64_t bn = b + gridDim.x;
+            pbeg = nbeg; pend = nend;
+            if (bn < B) {
+                const int64_t b2 = bn + gridDim.x;
+                if (b2 < B) { nbeg = ptr[b2 + vz]; nend = ptr[b2 + 1 + vz]; }
+                const int pc = pend - pbeg;
+                if (slot < RPB && pc > 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = slot + u * RPB;
+                        pv[u] = ld4(x + (int64_t)(pbeg + (r < pc ? r : 0)) * H + 4 * sub);
+                    }
+                }
+                if (t < O) ptgt = target[bn * O + t];
+            }
+        }
         // ---- pool (rows kept in LDS for the pool backward when they fit)
         float4 acc = f4zero();
         if (slot < RPB) {
-            // eight rows requested before the first is used (a use right behind its load keeps one load in flight: written
-            // as load / store / add per row this loop was ~7 dependent round trips per graph)
-            for (int r0 = slot; r0 < cnt; r0 += 8 * RPB) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                       // the prefetched batch
+                const int r = slot + u * RPB;
+                if (r < cnt) {
+                    if (in_lds) *reinterpret_cast<float4*>(&xs[r * H + 4 * sub]) = v0[u];
+                    acc = add4(acc, v0[u]);
+                }
+            }
+            // further batches (graphs of more than 8 * RPB rows): eight rows requested before the first is used
+            for (int r0 = slot + 8 * RPB; r0 < cnt; r0 += 8 * RPB) {
                 float4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -293,14 +348,14 @@ __global__ __launch_bounds__(256) void head_train_kernel(
         // ---- Linear -> LeakyReLU -> Dropout
         float hv = 0.f, dact = 0.f;
         if (t < H) {
-            float v = b0[t];
+            float v = b0t;
 #pragma unroll 8
             for (int a = 0; a < H; ++a) v = fmaf(w0s[t * HP + a], pp[a], v);
             // d/dpre of dropout(leaky_relu(pre)), from the same draw the forward applies
             float d = 1.0f;
             if (act.thr16) {
                 const uint64_t flat = (uint64_t)(b * H + t);
-                const uint64_t z = act_hash64(act.seed, (uint64_t)act.step[0], flat >> 2);
+                const uint64_t z = act_hash64(act.seed, stepv, flat >> 2);
                 const bool keep = ((uint32_t)(z >> (16 * (flat & 3))) & 0xFFFFu) >= act.thr16;
                 d = keep ? act.keep_scale : 0.f;
             }
@@ -312,10 +367,10 @@ __global__ __launch_bounds__(256) void head_train_kernel(
         __syncthreads();
         // ---- Linear(H, O), criterion
         if (t < O) {
-            float v = b3[t];
+            float v = b3t;
             for (int a = 0; a < H; ++a) v = fmaf(w3s[t * H + a], hh[a], v);
             out[b * O + t] = v;
-            const float df = v - target[b * O + t];
+            const float df = v - tgt;
             const float ad = fabsf(df);
             float l, g;
             if (ad < beta) { l = 0.5f * df * df / beta; g = df / beta; }
@@ -367,7 +422,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(
                     const int64_t flat = (int64_t)(beg + r) * H + 4 * sub;
                     const float4 yy = in_lds ? *reinterpret_cast<const float4*>(&xs[r * H + 4 * sub]) : ld4(x + flat);
                     uint64_t z = 0;
-                    if (in_act.thr16) z = act_hash64(in_act.seed, (uint64_t)in_act.step[0], (uint64_t)flat >> 2);
+                    if (in_act.thr16) z = act_hash64(in_act.seed, in_stepv, (uint64_t)flat >> 2);
                     float vi[4] = {v.x, v.y, v.z, v.w};
                     const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
 #pragma unroll

@@ -407,6 +407,11 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         for (int b = 0; b < 4; ++b) dwoff[b] = base0 + ((((b ^ (m >> 1)) << 1) | (hi ^ (m & 1))) << 2);
     }
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nh * (KT / 8) + kq * GQ) * 64 + lane;
+#ifdef QOT_ADJ_SETPRIO
+    // static priority for the second-dispatched half of the workgroup (waves 4-7 share their SIMDs with waves 0-3 and lose
+    // the age-based arbitration on every phase): MI355X_MICROARCH.md, "Two waves per SIMD", item 4
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
 #pragma unroll 1
     for (int64_t it = 0;; ++it) {
