@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-sample-graphs", type=int, default=64)
     ap.add_argument("--no-lightpath", action="store_true", help="skip the separate LightpathGNN (configs[2]) measurement")
     ap.add_argument("--lightpath-steps", type=int, default=10)
+    ap.add_argument("--no-reference-scale", action="store_true",
+                    help="skip the reference-scale (V=75 H=16 B=512 / F=5 C=32 B=512) eager and replayed step times")
     return ap.parse_args()
 
 
@@ -241,6 +243,25 @@ def kernel_table(model, batch):
                                             P(ea), P(we), P(g.rowptr), P(colf), P(g.eid), P(ids32), P(out), P(stats), N, H, D,
                                             n_, B_, 0, 0.0, 0.0, 0, None),
         N * H * 4 + 8 * N + E * D * 4 + csr + 4 * E + 4 * N + n_ * 4 * H * 4)
+    # ... and, since r04, what the replayed step ACTUALLY runs for graphs of <= 128 nodes: the graph form (whole graphs per
+    # workgroup, score matrix and value table in LDS; csrc/tconv_graph.hip).  Algorithmic bytes as SURVEY 8(d) prices a conv
+    # (the projected table is 100 KB) + what the forward leaves for the backward (alpha, CSR-ordered edge features, sum alpha ea)
+    gsz = build_graph_index(batch.edge_index, N, slices=(batch.ptr, batch.edge_ptr) + tuple(batch.graph_sizes),
+                            node_ids=batch.node_ids)
+    max_e = int(batch.graph_sizes[1])
+    ldm = lib.qot_tconv_graph_ldm(n_)
+    Mm, Pm = f(n_, ldm), f(n_, D)
+    alpha, ea_csr, aa = torch.empty(E, device=dev), torch.empty(E, D, device=dev), torch.empty(N, D, device=dev)
+    step1 = torch.ones((), dtype=torch.long, device=dev)
+    add("tconv_fwd_graph", lambda: _lib.call("qot_tconv_fwd_graph", t4, 4 * H, Mm, Pm, we, ea, gsz.rowptr, gsz.colf, gsz.eid,
+                                             gsz.row, out, alpha, ea_csr, aa, n_, B_, max_e, H, D, 1, 0.01, 0.5, 1234, step1),
+        N * H * 4 + E * D * 4 + csr + 8 * E + E * 4 + E * D * 4 + N * D * 4 + n_ * 4 * H * 4)
+    blocks, rowlen = lib.qot_tconv_bwd_graph_blocks(B_), lib.qot_tconv_graph_row_floats(n_, H, D)
+    partials = torch.empty(blocks, rowlen, device=dev)
+    add("tconv_bwd_graph", lambda: _lib.call("qot_tconv_bwd_graph", gout, out, 0.01, 0.5, 1234, step1, t4, 4 * H, we, ea_csr,
+                                             alpha, aa, gsz.rowptr, gsz.colf, gsz.row, gsz.rowptr_t, gsz.col_t, gsz.pos_t,
+                                             partials, n_, B_, max_e, H, D),
+        2 * N * H * 4 + E * D * 4 + 2 * csr + 12 * E + E * 4 + N * D * 4 + blocks * rowlen * 4)
     add("tconv_bwd_dst", lambda: _lib.call("qot_tconv_bwd_dst", P(gout), off(qkvs, 0), off(qkvs, H), off(qkvs, 2 * H),
                                            4 * H, P(ea), P(we), P(stats), P(g.rowptr), P(g.col), P(g.eid), None,
                                            off(gq, 0), off(gq, 3 * H), 4 * H, P(escr), P(delta), P(pds), P(pal),
@@ -393,6 +414,64 @@ def lightpath_measurement(device, steps):
                      "traffic": None, "alg_flops_per_launch": kflops, "alg_bytes_per_launch": 8 * N * W + 4 * W * W,
                      "ms_per_launch": ms_k},
     }
+
+
+def reference_scale_measurement(device, steps=100):
+    """SURVEY 8(d)'s "reference-scale sanity config" -- the sizes the reference's user actually runs: TopologicalGNN V = 75,
+    H = 16, B = 512 (topological_training/train.py:38,50-52) and LightpathGNN F = 5, C = 32, B = 512
+    (lightpath_training/train.py:39,52).  A SEPARATE object of the JSON line (never ``value``).  One train step = the step
+    body of the reference's loop on a cached batch of an HBM-resident shard (``harness.StepReplayer._step``): eager launches,
+    and the same step replayed as a HIP graph (what ``harness.fit(replay=True)`` does from a batch's third visit on)."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import harness as Hn, synthetic as S
+    from gnn_qot_estimation_amd.dp import FlatModel, FusedSGD
+    from gnn_qot_estimation_amd.loader import GraphLoader
+
+    def timed(fn, n):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {}
+    torch.manual_seed(0)
+    cases = (
+        ("topological", "TopologicalGNN V=75 H=16 edge_dim=4, B=512 (75 nodes, 150 directed edges per graph)",
+         lambda: q.TopologicalGNN(75, 16, 3, 4, dropout_p=0.5), lambda: S.topological_batch(2, 512, n=75, e=150)),
+        ("lightpath", "LightpathGNN F=5 C=32 heads=4, B=512 (chain graphs of 2..20 nodes)",
+         lambda: q.LightpathGNN(5, 32, 3, 1, dropout_p=0.5), lambda: S.lightpath_batch(512)),
+    )
+    for kind, what, make_model, make_batch_ in cases:
+        b = make_batch_()
+        graphs = b.num_graphs
+        shard = q.PackedGraphs.from_batch(b).to_device(device)
+        loader = GraphLoader(shard, graphs, shuffle=False, device=device, cache_batches=True)
+        data = next(iter(loader))
+        model = make_model().to(device).train()
+        flat = FlatModel(model)
+        opt = FusedSGD(flat, lr=0.01, momentum=0.9, device_lr=True)
+        rp = Hn.StepReplayer(model, kind, 3, device, flat, opt)
+        assert rp.run(data, True)                       # first visit: eager (builds and caches the graph index)
+        eager_ms = timed(lambda: rp._step(data, True), steps)
+        assert rp.run(data, True)                       # second visit: captured
+        assert (id(data), True) in rp.graphs
+        replay_ms = timed(lambda: rp.run(data, True), steps)
+        loss = float(rp._loss.item())
+        if not (loss == loss):
+            raise SystemExit(f"reference scale {kind}: non-finite loss")
+        out[kind] = {"workload": what, "graphs": graphs, "nodes": int(b.num_nodes), "edges": int(b.num_edges),
+                     "eager_ms_per_step": eager_ms, "replayed_ms_per_step": replay_ms,
+                     "eager_graphs_per_s": graphs / (eager_ms * 1e-3), "replayed_graphs_per_s": graphs / (replay_ms * 1e-3),
+                     "final_loss": loss}
+        del rp, flat, opt, model, loader, shard
+        torch.cuda.empty_cache()
+    out["note"] = ("cached batch of an HBM-resident shard, dropout 0.5, SGD momentum 0.9, SmoothL1; eager = host launches "
+                   "(host-bound at this size), replayed = the whole step as one HIP graph")
+    return out
 
 
 def spawn_ranks(args) -> int:
@@ -560,6 +639,8 @@ def main():
             del step, batch, model
             torch.cuda.empty_cache()
             res["lightpath"] = lightpath_measurement(device, args.lightpath_steps)
+        if world == 1 and not args.no_reference_scale:
+            res["reference_scale"] = reference_scale_measurement(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)
         print(json.dumps(res))

@@ -146,6 +146,14 @@ class PackedGraphs:
         edges = torch.tensor([0] + [g.num_edges for g in graphs], dtype=torch.long).cumsum(0)
         return cls(b.ptr.clone(), edges, b.edge_index, b.edge_attr, b.node_ids, b.x, b.y, b.uniform_node_ids)
 
+    @classmethod
+    def from_batch(cls, b: Batch) -> "PackedGraphs":
+        """A collated ``Batch`` (host tensors, with its ``edge_ptr``) as a shard: the same flat tensors, no copy."""
+        if getattr(b, "edge_ptr", None) is None:
+            raise ValueError("the batch carries no per-graph edge slices (edge_ptr)")
+        return cls(b.ptr.clone(), b.edge_ptr.clone(), b.edge_index, b.edge_attr, b.node_ids, b.x, b.y,
+                   getattr(b, "uniform_node_ids", None))
+
     def pin(self) -> "PackedGraphs":
         for name in ("edge_index", "edge_attr", "node_ids", "x", "y"):
             t = getattr(self, name)
