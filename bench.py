@@ -86,9 +86,14 @@ class TrainStep:
         self.loss = torch.zeros((), device=batch.y.device)
         self.graph_fb = None
         self.graph_opt = None
-        self.graph_multi = None              # steps_per_graph whole steps in one graph (N = 1)
-        self.spg = max(1, int(steps_per_graph)) if world == 1 else 1
+        self.graph_multi = None              # steps_per_graph whole steps in one graph
+        # N > 1 (or BENCH_FORCE_DP=1: the same code path on a single-rank group, how the one-GPU box exercises it): the
+        # step has an exchange -- pack, ONE flat-gradient all-reduce -- between backward and update
+        self.dp = world > 1 or bool(os.environ.get("BENCH_FORCE_DP"))
+        self.spg = max(1, int(steps_per_graph))
         self.use_graph = use_graph
+        self.collective_in_graph = None      # True: the RCCL call is captured with the rest of the step
+        self.capture_error = None
 
     def _fwd_bwd(self):
         if not os.environ.get("BENCH_PREP_OUTSIDE"):
@@ -98,21 +103,27 @@ class TrainStep:
         # (written with the backward epilogue) and d loss / d out; then backward from the model output
         out, _, g = self.model.forward_loss(self.batch, self.y, loss_out=self.loss)
         out.backward(g)
-        if self.world > 1:
+        if self.dp:
             self.flat.gather_grads()         # one kernel packs all gradients into the flat buffer RCCL reduces
 
     def _update(self):
         # one rank: the pack rides in the update kernel (gradients read from their own tensors)
-        self.opt.step(grads=True if self.world == 1 else None)
+        self.opt.step(grads=None if self.dp else True)
+
+    def _exchange(self):
+        if self.dp:
+            self.flat.all_reduce_grads(force=True)
 
     def _eager(self):
         self._fwd_bwd()
-        self.flat.all_reduce_grads()
+        self._exchange()
         self._update()
 
     def capture(self):
-        """Capture forward+backward and the optimizer update as two HIP graphs; the RCCL
-        all-reduce stays an eager call between them (one launch per step)."""
+        """Capture WHOLE steps -- forward, backward, pack, the RCCL all-reduce of the flat gradient, update -- as one HIP
+        graph holding ``steps_per_graph`` of them, at every N (r04: RCCL 2.26 takes part in stream capture;
+        tests/test_gpu_dp.py).  A backend that cannot be captured (gloo in the CPU rehearsal) falls back to two graphs
+        with the eager collective between them, one step per replay; the line says which (``collective_in_graph``)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -120,18 +131,30 @@ class TrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        capturable = not self.dp or (dist.is_initialized() and dist.get_backend() == "nccl")
+        if capturable:
+            try:
+                self.graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb):
+                    self._eager()
+                if self.spg > 1:             # several whole steps per replay: every step still runs every kernel
+                    self.graph_multi = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_multi, pool=self.graph_fb.pool()):
+                        for _ in range(self.spg):
+                            self._eager()
+                self.collective_in_graph = self.dp
+                return
+            except Exception as e:           # noqa: BLE001 -- the runtime's refusal is recorded, the fallback measured
+                if not self.dp:
+                    raise
+                self.capture_error = repr(e)[:400]
+                self.graph_fb = self.graph_multi = None
+                torch.cuda.synchronize()
+        else:
+            self.capture_error = f"backend {dist.get_backend() if dist.is_initialized() else None} is not stream-capturable"
+        self.collective_in_graph = False
+        self.spg = 1
         self.graph_fb = torch.cuda.CUDAGraph()
-        if self.world == 1:                  # no exchange step: the optimizer rides in the same graph
-            with torch.cuda.graph(self.graph_fb):
-                self._fwd_bwd()
-                self._update()
-            if self.spg > 1:                 # several whole steps per replay: every step still runs every kernel
-                self.graph_multi = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_multi, pool=self.graph_fb.pool()):
-                    for _ in range(self.spg):
-                        self._fwd_bwd()
-                        self._update()
-            return
         with torch.cuda.graph(self.graph_fb):
             self._fwd_bwd()
         self.graph_opt = torch.cuda.CUDAGraph()
@@ -144,7 +167,7 @@ class TrainStep:
         else:
             self.graph_fb.replay()
             if self.graph_opt is not None:
-                self.flat.all_reduce_grads()
+                self._exchange()
                 self.graph_opt.replay()
 
     def run(self, n):
@@ -514,13 +537,37 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box
+    force_dp = bool(os.environ.get("BENCH_FORCE_DP"))
+    if world > 1 or force_dp:
+        # BENCH_BACKEND=gloo + BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box.
+        # BENCH_FORCE_DP=1 (at N = 1): the N > 1 step -- pack, RCCL all-reduce inside the captured step, plain update -- on a
+        # single-rank nccl group: the one-GPU box measures what the collective's launch costs the step (not a scaling number)
         backend = os.environ.get("BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kw = dict(rank=rank, world_size=world) if world == 1 else {}
+        # RCCL prints a version banner on STDOUT when its communicator comes up (first collective): keep stdout for the one
+        # JSON line -- the banner goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device, **kw)
+            else:
+                dist.init_process_group(backend, **kw)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -574,8 +621,8 @@ def main():
         raise SystemExit(f"non-finite loss {loss}")
     # the exchange step alone (outside the timed region): events around the flat-gradient all-reduce
     all_reduce_us = None
-    if world > 1:
-        all_reduce_us = event_time_ms(step.flat.all_reduce_grads, iters=20, warm=3) * 1e3
+    if step.dp and dist.is_initialized():
+        all_reduce_us = event_time_ms(lambda: step.flat.all_reduce_grads(force=True), iters=20, warm=3) * 1e3
         t = torch.tensor([all_reduce_us], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         all_reduce_us = float(t.item())
@@ -593,12 +640,15 @@ def main():
                                    "SGD momentum 0.9, SmoothL1; " + ("graph index cached across steps (BENCH_PREP_OUTSIDE: the HBM-resident, cached-batch loader mode; not the headline)" if os.environ.get("BENCH_PREP_OUTSIDE") else "CSR build included in every step"),
                        "graphs_per_gpu": CFG["B"], "global_batch": CFG["B"] * world, "distinct_graphs_per_gpu": CFG["B"],
                        "launch": "eager" if step.graph_fb is None else (
-                           f"hip-graph replay, {step.spg} whole steps (fwd+bwd+optimizer each) per graph" if step.graph_multi is not None
-                           else "hip-graph replay (fwd+bwd, optimizer)"),
+                           f"hip-graph replay, {step.spg} whole steps (fwd+bwd" + ("+pack+all-reduce" if step.dp else "") + "+optimizer each) per graph"
+                           if step.graph_multi is not None else
+                           ("hip-graph replay, one whole step per graph" if step.graph_opt is None
+                            else "hip-graph replay (fwd+bwd+pack | eager all-reduce | optimizer)")),
                        "steps_per_graph": step.spg if step.graph_multi is not None else 1,
+                       "collective_in_graph": step.collective_in_graph, "collective_capture_error": step.capture_error,
                        "parallelism": f"dp{world}", "final_loss": loss, "prime_steps": prime_steps,
-                       "collective_world_size": dist.get_world_size() if world > 1 else 1,
-                       "collective_backend": dist.get_backend() if world > 1 else None,
+                       "collective_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": dist.get_backend() if dist.is_initialized() else None,
                        "all_reduce_us": all_reduce_us,
                        "all_reduce_floats": int(step.flat.flat_grad.numel())},
         }
@@ -644,7 +694,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_graphs)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -175,13 +175,20 @@ class StepReplayer:
     runs eagerly (it also builds and caches the graph index), the second is captured, later ones replay.
     All captures share one memory pool (steps never overlap), the learning rate lives in device memory
     (``FusedSGD(device_lr=True)``), dropout draws come from the device-side counter.  Batches whose
-    forward raises (``ValueError``: no LUT node) are remembered and skipped.  Single process only: a
-    collective cannot sit inside these graphs.
+    forward raises (``ValueError``: no LUT node) are remembered and skipped.
+    Data parallel (r04): RCCL takes part in stream capture, so with ``collective=True`` (set by ``fit`` for a TopologicalGNN
+    run on more than one rank over the nccl backend) the captured step holds forward, backward, the pack of the gradients,
+    ONE all-reduce of the flat gradient and the update -- the N > 1 step is the N = 1 step plus that exchange.  Every rank
+    must visit the same sequence of batches (``_local_batches`` guarantees it).  LightpathGNN under data parallelism keeps
+    the eager loop: its BatchNorm exchange and the LUT skip are decided per global batch on the host.
     """
 
-    def __init__(self, model, kind: str, out_dim: int, device, flat: Optional[FlatModel], opt: Optional[FusedSGD]):
+    def __init__(self, model, kind: str, out_dim: int, device, flat: Optional[FlatModel], opt: Optional[FusedSGD],
+                 collective: bool = False):
         self.model, self.kind, self.out_dim, self.device = model, kind, out_dim, device
         self.flat, self.opt = flat, opt
+        self.collective = bool(collective)
+        self._scale: Dict[int, torch.Tensor] = {}      # per batch object: this rank's share of the global mean loss
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs: Dict[Tuple[int, bool], object] = {}
         self.visits: Dict[Tuple[int, bool], int] = {}
@@ -204,8 +211,21 @@ class StepReplayer:
             functional = lambda d: torch.func.functional_call(self.model, leaves, (d,))
             out, y = fwd(functional, data, self.out_dim)
             _, g = QF.smooth_l1_loss_and_grad(out, y, loss_out=self._loss)
+            if self.collective:
+                # this rank's share of the global mean loss (dp.loss_scale: one host-built scalar per batch object, made
+                # on the batch's first -- eager -- visit; a capture must not copy from pageable host memory)
+                sc = self._scale.get(id(data))
+                if sc is None:
+                    sc = self._scale[id(data)] = loss_scale(y.shape[0], self.device)
+                g = g * sc
             grads = torch.autograd.grad(out, list(leaves.values()), g, allow_unused=True)
-            self.opt.step(grads=list(grads))     # the pack into the flat gradient rides in the update kernel
+            if self.collective:
+                torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                           for gr, p in zip(grads, self.flat.params)], out=self.flat.flat_grad)
+                self.flat.all_reduce_grads(force=True)
+                self.opt.step()
+            else:
+                self.opt.step(grads=list(grads))     # the pack into the flat gradient rides in the update kernel
         else:
             with torch.no_grad():
                 out, y = fwd(self.model, data, self.out_dim)
@@ -257,7 +277,17 @@ def run_epoch(model, dataset, indices: range, *, kind: str, batch_size: int, out
     skipped = 0
     training = opt is not None
     model.train(training)
-    if replayer is not None and resident and world == 1:
+    shares_ok = True
+    if world > 1 and replayer is not None and replayer.collective:
+        # a replayed step holds the collective: every rank must hold graphs of every global batch (the split is a pure
+        # function of the indices, so every rank reaches the same verdict without talking)
+        costs = _graph_costs(dataset, indices)
+        for b0 in range(0, len(indices), batch_size):
+            nb = min(batch_size, len(indices) - b0)
+            for r in range(world):
+                lo, hi = graph_range(nb, r, world, costs=None if costs is None else costs[b0:b0 + nb])
+                shares_ok = shares_ok and hi > lo
+    if replayer is not None and resident and (world == 1 or (replayer.collective and training and shares_ok)):
         st = replayer.stats[training]
         st.buf.zero_()
         for data in loader:
@@ -355,9 +385,11 @@ def fit(model, dataset, *, kind: str = "topological", batch_size: int = 512, num
     flat.broadcast_params()
     rank, world = _rank_world()
     resident = isinstance(dataset, PackedGraphs) and dataset.device is not None
-    use_replay = (resident and world == 1) if replay is None else (bool(replay) and resident and world == 1)
+    # more than one rank: replayed steps hold the RCCL all-reduce (nccl backend, TopologicalGNN; StepReplayer docstring)
+    dp_ok = world == 1 or (kind == "topological" and dist.get_backend() == "nccl")
+    use_replay = (resident and dp_ok) if replay is None else (bool(replay) and resident and dp_ok)
     opt = FusedSGD(flat, lr=lr, momentum=momentum, device_lr=use_replay)
-    replayer = StepReplayer(model, kind, output_dim, device, flat, opt) if use_replay else None
+    replayer = StepReplayer(model, kind, output_dim, device, flat, opt, collective=world > 1) if use_replay else None
     criterion = torch.nn.SmoothL1Loss()
     hist = History()
     counter = 0

@@ -236,6 +236,96 @@ def test_rccl_single_rank_group_runs_the_avg_all_reduce():
     assert abs(got["scale"] - 1.0) < 1e-6
 
 
+def _rccl_capture_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import copy
+        import gnn_qot_estimation_amd as q
+        from gnn_qot_estimation_amd import dp, harness as Hn, synthetic as S
+        from gnn_qot_estimation_amd.loader import GraphLoader
+        # (1) the flat-gradient all-reduce of FlatModel inside a captured HIP graph, replayed three times
+        full, model = _build("topo", dev)
+        flat = dp.FlatModel(model)
+        flat.flat_grad.copy_(torch.arange(flat.numel, device=dev, dtype=torch.float32) / 7.0)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            flat.all_reduce_grads(force=True)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            flat.all_reduce_grads(force=True)
+        same = []
+        for k in range(3):
+            flat.flat_grad.mul_(1.5)
+            want = flat.flat_grad.clone()
+            g.replay()
+            torch.cuda.synchronize()
+            same.append(bool(torch.equal(flat.flat_grad, want)))
+        ret["captured_all_reduce"] = same
+        # (2) replayed training with the collective INSIDE every captured step == the same training without it
+        torch.manual_seed(0)
+        b = S.topological_batch(2, 96, n=12, e=30)
+        shard = q.PackedGraphs.from_batch(b).to_device(dev)
+        base = q.TopologicalGNN(12, 16, 3, 4, dropout_p=0.0).to(dev)
+        out = {}
+        for coll in (False, True):
+            m = copy.deepcopy(base)
+            fl = dp.FlatModel(m)
+            opt = dp.FusedSGD(fl, lr=0.05, momentum=0.9, device_lr=True)
+            opt.lr = 0.05
+            rp = Hn.StepReplayer(m, "topological", 3, dev, fl, opt, collective=coll)
+            for epoch in range(4):
+                Hn.run_epoch(m, shard, range(96), kind="topological", batch_size=32, out_dim=3, device=dev,
+                             criterion=torch.nn.SmoothL1Loss(), flat=fl, opt=opt, replayer=rp)
+            torch.cuda.synchronize()
+            out[coll] = (fl.flat_param.clone(), len(rp.graphs))
+        ret["graphs"] = (out[False][1], out[True][1])
+        ret["params_equal"] = bool(torch.equal(out[False][0], out[True][0]))
+        ret["params_moved"] = float((out[True][0] - dp.FlatModel(copy.deepcopy(base)).flat_param).abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_inside_captured_steps():
+    """RCCL takes part in stream capture (r04): ``FlatModel.all_reduce_grads(force=True)`` on the single-rank nccl group
+    captured in a HIP graph and replayed three times is bit-equal to its input each time; and the replayed train steps of
+    ``harness.StepReplayer(collective=True)`` -- forward, backward, pack, all-reduce, update in ONE graph -- leave exactly the
+    parameters the collective-free replay leaves (AVG over one rank is the identity).  The child is a fresh process of a
+    parent that has not touched the GPU."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_capture_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        got = dict(ret)
+    assert got["captured_all_reduce"] == [True, True, True], got
+    assert got["graphs"][0] >= 3 and got["graphs"][1] == got["graphs"][0], got
+    assert got["params_equal"] and got["params_moved"] > 1e-4, got
+
+
+def test_bench_forced_data_parallel_step_holds_the_collective_in_its_graph():
+    """``BENCH_FORCE_DP=1 python bench.py``: the N > 1 step (pack, flat-gradient all-reduce, plain update) on a
+    single-rank nccl group -- the line must say that the collective sits inside the captured multi-step graph."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DP="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-lightpath", "--no-reference-scale"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = line["config"]
+    assert cfg["collective_in_graph"] is True and cfg["collective_backend"] == "nccl", cfg
+    assert cfg["steps_per_graph"] == 4 and cfg["all_reduce_us"] > 0
+    assert cfg["final_loss"] == cfg["final_loss"]
+
+
 def test_bench_two_ranks_on_one_gpu_over_gloo_reports_the_collective():
     """``python bench.py --gpus 2`` (self-spawned ranks, SURVEY 8(e) / the driver's launch contract) rehearsed on the
     one-GPU box: ``BENCH_BACKEND=gloo BENCH_SHARE_GPU=1`` puts both ranks on cuda:0.  The children are fresh processes
@@ -259,5 +349,6 @@ def test_bench_two_ranks_on_one_gpu_over_gloo_reports_the_collective():
     assert line["n_gpus"] == 2 and cfg["collective_world_size"] == 2 and cfg["collective_backend"] == "gloo"
     assert cfg["global_batch"] == 2 * cfg["graphs_per_gpu"] and line["scaling"] == "weak"
     assert cfg["all_reduce_us"] is not None and cfg["all_reduce_us"] > 0 and cfg["all_reduce_floats"] > 1000
+    assert cfg["collective_in_graph"] is False and "gloo" in cfg["collective_capture_error"]     # gloo: the two-graph fallback
     assert cfg["final_loss"] == cfg["final_loss"] and abs(cfg["final_loss"]) < 1e3
     assert line["value"] > 0 and line["steps"] == 3
