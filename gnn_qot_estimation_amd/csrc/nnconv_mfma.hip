@@ -407,6 +407,9 @@ __global__ __launch_bounds__(512, 2) void nnconv_adjoint_dw64_kernel(
         for (int b = 0; b < 4; ++b) dwoff[b] = base0 + ((((b ^ (m >> 1)) << 1) | (hi ^ (m & 1))) << 2);
     }
     const float4* wp = reinterpret_cast<const float4*>(Wp) + ((int64_t)nh * (KT / 8) + kq * GQ) * 64 + lane;
+    // (r04, measured and not kept, tools/ab_adjoint.py, interleaved rounds in one process: static `s_setprio 1` for waves 4-7
+    // -- 172.7 us either way; the half index folded into the tile's XOR swizzle, i ^ ((g + 4 hi) & 7), which makes the
+    // transposed reads of the X^T U loop conflict-free -- 171.9 us either way: that loop does not wait for LDS bandwidth)
 #ifdef QOT_ADJ_SETPRIO
     // static priority for the second-dispatched half of the workgroup (waves 4-7 share their SIMDs with waves 0-3 and lose
     // the age-based arbitration on every phase): MI355X_MICROARCH.md, "Two waves per SIMD", item 4
