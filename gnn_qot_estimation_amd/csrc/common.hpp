@@ -128,11 +128,20 @@ struct ActParams {
     const int64_t* step;    // device-side step counter (graph-replay safe), may be NULL when thr16 == 0
 };
 
+// r04: three 32 x 32 -> 64 multiplies with hi ^ lo folds instead of SplitMix64's three 64 x 64 multiplies (nine quarter-rate
+// 32-bit multiplies on this part; the hash was 15 % of the TransformerConv forward).  The key (seed, step) is wave-uniform in
+// every caller.  Checked on 2 M consecutive indices for several keys (keep rates at p = 0.1 / 0.5 / 0.9 of all four 16-bit
+// draws, per-bit bias, correlation between the draws, between neighbouring indices at strides 1 .. 25 600 and between
+// consecutive steps): every deviation <= 2.2e-3, the sampling noise of the check (SplitMix64 reads the same).
 __device__ __forceinline__ uint64_t act_hash64(uint64_t seed, uint64_t step, uint64_t idx4) {
-    uint64_t z = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (idx4 * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    const uint64_t k = seed ^ (step * 0x9E3779B97F4A7C15ull);
+    const uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
+    const uint64_t p = (uint64_t)((uint32_t)idx4 ^ k0) * 0x9E3779B1u;
+    const uint32_t a = (uint32_t)(p >> 32) ^ (uint32_t)p ^ (uint32_t)(idx4 >> 32) ^ k1;
+    const uint64_t q = (uint64_t)a * 0x85EBCA77u;
+    const uint64_t r = (uint64_t)(a ^ k0 ^ 0x68E31DA4u) * 0xC2B2AE3Du;
+    const uint32_t w0 = (uint32_t)(q >> 32) ^ (uint32_t)q, w1 = (uint32_t)(r >> 32) ^ (uint32_t)r;
+    return ((uint64_t)w1 << 32) | w0;
 }
 
 __device__ __forceinline__ float act_apply1(float v, const ActParams& a, uint64_t flat) {

@@ -57,17 +57,15 @@ __device__ unsigned long long g_tg_stamps[16];
 // together a dependent global round trip costs 0.7-1 us, so the count of SERIALISED trips -- not bytes -- sets the time
 // (first version: ~10 trips, 19.5 us; measured with the diagnostic build's stamps, tools/bench_tconv_graph.py).
 struct TgFwdLds {
-    int m, tv, ts, p, slot0, slot_floats, rp, col, al, ea, aa;   // float offsets (rp .. aa: inside a slot)
+    int tv, ts, slot0, slot_floats, rp, col, al, ea, aa;   // float offsets (rp .. aa: inside a slot)
     size_t bytes(int ns) const { return (size_t)(slot0 + ns * slot_floats) * 4; }
 };
 __host__ __device__ inline TgFwdLds tg_fwd_lds(int n, int H, int D, int max_e) {
     TgFwdLds L;
     const int me = pad4(max_e > 0 ? max_e : 1);
-    L.m = 0;
-    L.tv = L.m + n * pad4(n);
-    L.ts = L.tv + n * H;
-    L.p = L.ts + n * H;
-    L.slot0 = L.p + pad4(n * D);
+    L.tv = 0;                                    // (the score matrix M and P stay in L2: one lookup per edge, in the same
+    L.ts = L.tv + n * H;                         //  round trip as the edge's features; 40 KB less to stage per workgroup)
+    L.slot0 = L.ts + n * H;
     L.rp = 0;
     L.col = L.rp + pad4(n + 1);
     L.al = L.col + me;
@@ -94,10 +92,8 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
     const int ldm = pad4(n);
     const int NS = (int)blockDim.x >> 8;
     const int slot = (int)threadIdx.x >> 8, t = (int)threadIdx.x & 255;
-    float* sM = lds + L.m;
     float* sTv = lds + L.tv;
     float* sTs = lds + L.ts;
-    float* sP = lds + L.p;
     float* sb = lds + L.slot0 + slot * L.slot_floats;
     int* sRp = reinterpret_cast<int*>(sb + L.rp);      // RAW index slots (global), normalised by e0 where read
     int* sCol = reinterpret_cast<int*>(sb + L.col);
@@ -106,34 +102,35 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
     float* sAa = sb + L.aa;
 
     TG_STAMP_DECL
+#ifdef QOT_DIAG
+    const int tg_var = g_tg_variant;       // forward ablation bits: 16 no stage C, 32 no stage B, 64 no edge staging (A)
+#endif
     const int sub = t % TPR, grp = t / TPR, c0 = CPL * sub;
     // ---- trip 1: the first graph's row pointers, the tables (one batch of loads), the per-thread constants
     const int64_t bfirst = (int64_t)blockIdx.x * NS + slot;
     int rp_raw = 0;
     if (bfirst < B && t <= n) rp_raw = rowptr[bfirst * n + t];
     {
-        const int nM4 = n * ldm / 4, nT4 = n * H / 4, total = nM4 + 2 * nT4;
-        constexpr int TB = 6;
+        const int nT4 = n * H / 4, total = 2 * nT4;
+        constexpr int TB = 4;
         for (int base = threadIdx.x; base < total; base += TB * (int)blockDim.x) {
             float4 v[TB];
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 const int i = base + u * (int)blockDim.x;
-                if (i < nM4) v[u] = ld4(M + 4 * i);
-                else if (i < total) {
-                    const int k = i - nM4, kk = k < nT4 ? k : k - nT4;
+                if (i < total) {
+                    const int kk = i < nT4 ? i : i - nT4;
                     const int r = (4 * kk) / H, c = (4 * kk) % H;
-                    v[u] = ld4((k < nT4 ? tv : tskip) + (int64_t)r * ld + c);
+                    v[u] = ld4((i < nT4 ? tv : tskip) + (int64_t)r * ld + c);
                 }
             }
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 const int i = base + u * (int)blockDim.x;
-                if (i < total) st4((i < nM4 ? sM : sTv - 4 * nM4) + 4 * i, v[u]);     // sTs follows sTv
+                if (i < total) st4(sTv + 4 * i, v[u]);                 // sTs follows sTv
             }
         }
     }
-    for (int i = threadIdx.x; i < n * D; i += blockDim.x) sP[i] = Pm[i];
     const uint64_t stepv = act.thr16 ? (uint64_t)act.step[0] : 0;        // read once (see act_apply4s)
     float wl[CPL][D];
 #pragma unroll
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
             eb = eb < 0 ? 0 : (eb > max_e ? max_e : eb);       // (the index build has checked the slices; memory safety)
         }
         // ---- A: trip 2 = index slice, trip 3 = edge features; the logits are formed here (one thread per edge)
-        for (int pc = 0; pc < eb; pc += 256 * EB) {
+        for (int pc = 0; pc < (TG_VAR(64) ? 0 : eb); pc += 256 * EB) {
             int cj[EB], rw[EB];
             int64_t ei[EB];
 #pragma unroll
@@ -170,28 +167,32 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
                 rw[u] = row[e0 + pp];
                 ei[u] = eid[e0 + pp];
             }
-            float ev[EB][D];
+            float ev[EB][D], pr[EB][D], mv[EB];
+            int jj[EB], rr[EB];
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
+                jj[u] = cj[u] < 0 ? 0 : (cj[u] >= n ? n - 1 : cj[u]);
+                const int r = rw[u] - (int)node0;
+                rr[u] = r < 0 ? 0 : (r >= n ? n - 1 : r);
+                mv[u] = M[rr[u] * ldm + jj[u]];                          // L2-resident: the same round trip as the features
                 if constexpr (D == 4) {
                     const float4 q = ld4(ea + ei[u] * 4);
                     ev[u][0] = q.x; ev[u][1] = q.y; ev[u][2] = q.z; ev[u][3] = q.w;
+                    const float4 pq = ld4(Pm + rr[u] * 4);
+                    pr[u][0] = pq.x; pr[u][1] = pq.y; pr[u][2] = pq.z; pr[u][3] = pq.w;
                 } else {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) ev[u][d] = ea[ei[u] * D + d];
+                    for (int d = 0; d < D; ++d) { ev[u][d] = ea[ei[u] * D + d]; pr[u][d] = Pm[rr[u] * D + d]; }
                 }
             }
 #pragma unroll
             for (int u = 0; u < EB; ++u) {
                 const int p = pc + t + 256 * u;
                 if (p < eb) {
-                    const int j = cj[u] < 0 ? 0 : (cj[u] >= n ? n - 1 : cj[u]);
-                    int r = rw[u] - (int)node0;
-                    r = r < 0 ? 0 : (r >= n ? n - 1 : r);
-                    float s = sM[r * ldm + j];
+                    float s = mv[u];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) s = fmaf(sP[r * D + d], ev[u][d], s);
-                    sCol[p] = j;
+                    for (int d = 0; d < D; ++d) s = fmaf(pr[u][d], ev[u][d], s);
+                    sCol[p] = jj[u];
                     sAl[p] = s;
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
         __syncthreads();
         TG_STAMP(1)
         // ---- B: edge softmax, two lanes per destination (a quad per destination -- two rounds of 64 -- measured slower)
-        if (live) {
+        if (live && !TG_VAR(32)) {
             const int l = t & 1;
             for (int r = t >> 1; r < n; r += 128) {
                 int beg = sRp[r] - e0, end = sRp[r + 1] - e0;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
         __syncthreads();
         TG_STAMP(2)
         // ---- C: aggregate, root term, activation
-        if (live) {
+        if (live && !TG_VAR(16)) {
             for (int r = grp; r < n; r += G) {
                 int beg = sRp[r] - e0, end = sRp[r + 1] - e0;
                 beg = beg < 0 ? 0 : (beg > eb ? eb : beg);
@@ -278,9 +279,10 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
                     for (int d = 0; d < D; ++d)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) oc[c] = fmaf(wl[4 * v + c][d], ad[d], oc[c]);
-                    st4(out + i * H + c0 + 4 * v,
-                        act_apply4s(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w), act, stepv,
-                                    (uint64_t)(i * H + c0 + 4 * v) >> 2));
+                    const float4 o4 = TG_VAR(256) ? make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w)
+                                                  : act_apply4s(make_float4(oc[0] + sk.x, oc[1] + sk.y, oc[2] + sk.z, oc[3] + sk.w),
+                                                                act, stepv, (uint64_t)(i * H + c0 + 4 * v) >> 2);
+                    if (!TG_VAR(128) || o4.x == 12345.678f) st4(out + i * H + c0 + 4 * v, o4);
                 }
             }
             for (int p = t; p < eb; p += 256) alpha[e0 + p] = sAl[p];

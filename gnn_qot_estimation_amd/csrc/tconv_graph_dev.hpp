@@ -133,10 +133,11 @@ __host__ __device__ inline int tg_bwd_scores_lds_floats(int n, int H, int D) {
     return a > b ? a : b;
 }
 
-// sum_{k in [k0, k1)} x[k * xs] * y[k * ys]: eight terms' operands requested before the first product
+// sum_{k in [k0, k1)} x[k * xs] * y[k * ys]: sixteen terms' operands requested before the first product (a batch is one
+// L2 round trip; the jobs of this launch are chains of them)
 __device__ __forceinline__ float tg_strided_dot(const float* __restrict__ x, int64_t xs, const float* __restrict__ y, int64_t ys,
                                                 int k0, int k1) {
-    constexpr int U = 8;
+    constexpr int U = 16;
     float acc = 0.f;
     for (int k = k0; k < k1; k += U) {
         float a[U], b[U];
@@ -195,17 +196,20 @@ __device__ __forceinline__ void table_project_bwd_scores_body(const float* __res
         __syncthreads();
         float acc = 0.f, sb = 0.f;
         int vv = ph;
-        for (; vv + 7 * PH < n; vv += 8 * PH) {
-            float tv[8];
+        for (; vv < n; vv += 16 * PH) {
+            float tv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tv[u] = table[(int64_t)(vv + u * PH) * H + a];
+            for (int u = 0; u < 16; ++u) {
+                const int v2 = vv + u * PH;
+                tv[u] = table[(int64_t)(v2 < n ? v2 : vv) * H + a];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const float gv = gs[vv + u * PH]; acc = fmaf(gv, tv[u], acc); sb += gv; }
-        }
-        for (; vv < n; vv += PH) {
-            const float gv = gs[vv];
-            acc = fmaf(gv, table[(int64_t)vv * H + a], acc);
-            sb += gv;
+            for (int u = 0; u < 16; ++u) {
+                const int v2 = vv + u * PH;
+                const float gv = v2 < n ? gs[v2] : 0.f;
+                acc = fmaf(gv, tv[u], acc);
+                sb += gv;
+            }
         }
         red[threadIdx.x] = acc;
         redb[threadIdx.x] = sb;
@@ -244,16 +248,16 @@ __device__ __forceinline__ void table_project_bwd_scores_body(const float* __res
         }
         __syncthreads();
         float acc = 0.f;
-        for (int c0 = ph; c0 < 4 * H; c0 += 8 * PH) {              // 4H / PH trips: a multiple of 8 for every width
-            float wv[8];
+        for (int c0 = ph; c0 < 4 * H; c0 += 16 * PH) {             // 4H / PH trips: a multiple of 16 for every width
+            float wv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int c = c0 + u * PH;
                 const int cc = c < 4 * H ? c : ph;
                 wv[u] = proj_w(p, cc / H)[(int64_t)(cc % H) * H + a];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int c = c0 + u * PH;
                 if (c < 4 * H) acc = fmaf(gs[c], wv[u], acc);
             }

@@ -76,6 +76,13 @@ if hasattr(lib, "qot_debug_tg_variant") and not os.environ.get("TG_STAMPS"):
         abl[name] = timeit(jobs["bwd_graph"])
     lib.qot_debug_tg_variant(0)
     print(json.dumps({"bwd_graph ablation (us)": abl}))
+    abl = {}
+    for name, v in (("full", 0), ("no stage C", 16), ("no stage B", 32), ("no edge staging", 64), ("no B, C", 48), ("nothing but the tables", 112),
+                    ("C without its output stores", 128), ("C without the activation (hash)", 256)):
+        lib.qot_debug_tg_variant(v)
+        abl[name] = timeit(jobs["fwd_graph"])
+    lib.qot_debug_tg_variant(0)
+    print(json.dumps({"fwd_graph ablation (us)": abl}))
 if hasattr(lib, "qot_debug_tg_stamps") and os.environ.get("TG_STAMPS"):
     lib.qot_debug_tg_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     names = ["fwd trip 1 (tables, row pointers) + barrier", "fwd A stage graph, logits", "fwd B softmax",
