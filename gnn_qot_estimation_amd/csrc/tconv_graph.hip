@@ -100,11 +100,11 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
     float* sAl = sb + L.al;
     float* sEa = sb + L.ea;
     float* sAa = sb + L.aa;
+#ifdef QOT_DIAG
+    const int tg_var = g_tg_variant;       // forward ablation bits: 16 no stage C, 32 no stage B, 64 no edge staging (A),
+#endif                                     // 128 no output stores, 256 no activation, 512 no table staging
 
     TG_STAMP_DECL
-#ifdef QOT_DIAG
-    const int tg_var = g_tg_variant;       // forward ablation bits: 16 no stage C, 32 no stage B, 64 no edge staging (A)
-#endif
     const int sub = t % TPR, grp = t / TPR, c0 = CPL * sub;
     // ---- trip 1: the first graph's row pointers, the tables (one batch of loads), the per-thread constants
     const int64_t bfirst = (int64_t)blockIdx.x * NS + slot;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void tconv_fwd_graph_kernel(
     {
         const int nT4 = n * H / 4, total = 2 * nT4;
         constexpr int TB = 4;
-        for (int base = threadIdx.x; base < total; base += TB * (int)blockDim.x) {
+        for (int base = threadIdx.x; base < (TG_VAR(512) ? 0 : total); base += TB * (int)blockDim.x) {
             float4 v[TB];
 #pragma unroll
             for (int u = 0; u < TB; ++u) {

@@ -78,7 +78,8 @@ if hasattr(lib, "qot_debug_tg_variant") and not os.environ.get("TG_STAMPS"):
     print(json.dumps({"bwd_graph ablation (us)": abl}))
     abl = {}
     for name, v in (("full", 0), ("no stage C", 16), ("no stage B", 32), ("no edge staging", 64), ("no B, C", 48), ("nothing but the tables", 112),
-                    ("C without its output stores", 128), ("C without the activation (hash)", 256)):
+                    ("C without its output stores", 128), ("C without the activation (hash)", 256),
+                    ("nothing at all (launch, barriers, per-thread constants)", 624)):
         lib.qot_debug_tg_variant(v)
         abl[name] = timeit(jobs["fwd_graph"])
     lib.qot_debug_tg_variant(0)
