@@ -107,6 +107,7 @@ SIGNATURES = {
     "qot_head_fwd_loss": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _p, _f, _p, _p, _p]),
     "qot_head_train": (_int, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p, _int,
                               _f, _f, _u64, _p, _p]),
+    "qot_head_train_blocks": (_int, [_i64, _int]),
     "qot_head_bwd_workspace_floats": (_sz, [_int, _int]),
     "qot_head_bwd_blocks": (_int, [_i64]),
     "qot_head_bwd": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _f, _u64, _p,

@@ -458,6 +458,274 @@ __global__ __launch_bounds__(256) void head_train_kernel(
     if (t < O) part[H * H + H + O * H + t] = ab3;
 }
 
+// ---- the same, GB = 256 / H graphs per pass (r04) ------------------------------------------------------------------------
+// head_train_kernel walks ONE graph at a time: eight barrier-separated phases per graph with 64 of 256 threads busy in the
+// two matrix-vector products, the graph's rows through LDS.  Here a pass takes GB graphs (4 at H = 64): thread (g, o) owns
+// output o of graph g in every dense phase (all 256 threads busy, one barrier per phase per GB graphs), a graph's rows belong
+// to FOUR lane groups (H / 4 lanes each) that keep them in REGISTERS from the pool to the pool backward (up to 32 rows per
+// group = 128 rows per graph; rows beyond are read again), and the per-thread partial sums of the bias / W3 / column-sum
+// gradients meet once per kernel instead of once per graph.  Same outputs and partial-row layout as head_train_kernel.
+constexpr int kHeadKeep = 32;            // rows FOUR lane groups per graph would keep each (128 rows per graph in registers)
+#ifndef QOT_HEAD_THREADS
+#define QOT_HEAD_THREADS 512       /* measured at cfg2: 256 threads 20.4 us, 512 17.3 us, 1024 23.8 us (64 B/lane of scratch) */
+#endif
+constexpr int kHeadThreads = QOT_HEAD_THREADS;
+#ifdef QOT_DIAG
+__device__ int g_head_variant;           // ablation bits (tools/bench_head.py): 1 no pool backward, 2 no dense phases, 4 no row loads
+#define HD_VAR(bit) (hd_var & (bit))
+#else
+#define HD_VAR(bit) 0
+#endif
+
+template <int H, int NT>
+__global__ __launch_bounds__(NT) void head_train_batched_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ ptr, const float* __restrict__ w0,
+    const float* __restrict__ b0, const float* __restrict__ w3, const float* __restrict__ b3,
+    const float* __restrict__ target, float beta, float inv_n, float* __restrict__ out, float* __restrict__ grad_out,
+    float* __restrict__ loss_rows, float* __restrict__ gx, float* __restrict__ partials, int64_t B, int O, ActParams act,
+    int fold, ActParams in_act) {
+    constexpr int TPR = H / 4, RPB = NT / TPR;            // lane groups of the workgroup
+    constexpr int GB = 256 / H;                           // graphs per pass (GB * H = 256 dense outputs)
+    constexpr int SPG = RPB / GB;                         // lane groups per graph (16 at NT = 1024)
+    constexpr int KS = NT / 256;                          // threads per dense output (adjacent lanes: DPP sums)
+    constexpr int KR = kHeadKeep * 4 / SPG;               // rows a lane group keeps (8 at NT = 1024): 128 rows per graph
+    constexpr int PER = H * H / NT;                       // gW0 entries per thread
+    constexpr int HP = H + 1;
+    static_assert(KS == 1 || KS == 2 || KS == 4, "dense outputs are summed inside a quad");
+    static_assert(H % (4 * KS) == 0 && PER >= 1, "width");
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* w0s = dyn;                         // [H][H + 1]
+    float* w3s = w0s + H * HP;                // [8][H]
+    __shared__ float4 cred[NT > 640 ? NT : 640];          // lane-group partials; at the end [O + 2][256] floats
+    __shared__ __attribute__((aligned(16))) float pp[GB][H];
+    __shared__ __attribute__((aligned(16))) float hh[GB][H];
+    __shared__ __attribute__((aligned(16))) float gh[GB][H];
+    __shared__ __attribute__((aligned(16))) float gp[GB][H];
+    __shared__ float go[GB][8];
+    __shared__ float lrow[GB][8];
+    __shared__ int pb[GB + 1];
+    const int t = threadIdx.x;
+#ifdef QOT_DIAG
+    const int hd_var = g_head_variant;
+#endif
+    const int sub = t % TPR, slot = t / TPR;
+    const int gs = slot / SPG, sr = slot % SPG;           // my lane group's graph (of the pass) and its share of the rows
+    const int part = t % KS, od = t / KS;                 // dense phases: output od = (g, o), inner-index share `part`
+    const int g = od / H, o = od % H;
+    const int64_t npass = (B + GB - 1) / GB;
+    // the first pass's graph boundaries are requested together with the weights (one round trip instead of two)
+    int pb_first = 0;
+    if (t <= GB && (int64_t)blockIdx.x < npass) {
+        const int64_t bb = (int64_t)blockIdx.x * GB + t;
+        pb_first = ptr[bb < B ? bb : B];
+    }
+    for (int e = t; e < H * H; e += NT) w0s[(e / H) * HP + e % H] = w0[e];
+    for (int e = t; e < O * H; e += NT) w3s[e] = w3[e];
+    const uint64_t stepv = act.thr16 ? (uint64_t)act.step[0] : 0;
+    const uint64_t in_stepv = (fold && in_act.thr16) ? (uint64_t)in_act.step[0] : 0;
+    const float b0o = b0[o];
+    float aw0[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) aw0[e] = 0.f;
+    float ab0p = 0.f, aw3p[8], ab3p = 0.f;                // (held by the part == 0 lane of an output)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw3p[e] = 0.f;
+    float4 acs = f4zero();
+    for (int64_t ps = blockIdx.x; ps < npass; ps += gridDim.x) {
+        const int64_t b0g = ps * GB;
+        __syncthreads();                                  // the previous pass is done with pb / gp
+        if (t <= GB) {
+            const int64_t bb = b0g + t;
+            pb[t] = ps == (int64_t)blockIdx.x ? pb_first : ptr[bb < B ? bb : B];
+        }
+        __syncthreads();
+        // ---- pool: my lane group's rows of its graph, kept in registers
+        const bool live = b0g + gs < B;
+        const int beg = pb[gs], cnt = live ? pb[gs + 1] - beg : 0;
+        float4 v[KR];
+        float4 acc = f4zero();
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int r = sr + SPG * k;
+            v[k] = (r < cnt && !HD_VAR(4)) ? ld4(x + (int64_t)(beg + r) * H + 4 * sub) : f4zero();
+        }
+#pragma unroll
+        for (int k = 0; k < KR; ++k) acc = add4(acc, v[k]);
+        for (int r = sr + SPG * KR; r < cnt; r += SPG) acc = add4(acc, ld4(x + (int64_t)(beg + r) * H + 4 * sub));
+        cred[t] = acc;
+        __syncthreads();
+        if (t < GB * TPR) {
+            const int gg = t / TPR, sb = t % TPR;
+            float4 s4 = cred[(gg * SPG) * TPR + sb];
+            for (int q = 1; q < SPG; ++q) s4 = add4(s4, cred[(gg * SPG + q) * TPR + sb]);
+            const int c2 = pb[gg + 1] - pb[gg];
+            s4 = scale4(1.0f / (float)(c2 > 1 ? c2 : 1), s4);
+            pp[gg][4 * sb] = s4.x; pp[gg][4 * sb + 1] = s4.y; pp[gg][4 * sb + 2] = s4.z; pp[gg][4 * sb + 3] = s4.w;
+        }
+        __syncthreads();
+        // ---- Linear -> LeakyReLU -> Dropout: output o of graph g, the inner index split over KS adjacent lanes
+        const int64_t bg = b0g + g;
+        float hv = 0.f, dact = 0.f;
+        {
+            float a0 = 0.f;
+            if (!HD_VAR(2)) {
+#pragma unroll
+                for (int a = part * (H / KS); a < (part + 1) * (H / KS); ++a) a0 = fmaf(w0s[o * HP + a], pp[g][a], a0);
+            }
+            if (KS >= 2) a0 += dpp_move<0xB1>(a0);
+            if (KS >= 4) a0 += dpp_move<0x4E>(a0);
+            const float vv = a0 + b0o;
+            float d = 1.0f;
+            if (act.thr16) {
+                const uint64_t flat = (uint64_t)(bg * H + o);
+                const uint64_t z = act_hash64(act.seed, stepv, flat >> 2);
+                const bool keep = ((uint32_t)(z >> (16 * (flat & 3))) & 0xFFFFu) >= act.thr16;
+                d = keep ? act.keep_scale : 0.f;
+            }
+            d *= (vv > 0.f) ? 1.0f : act.slope;
+            hv = vv * d;
+            dact = d;
+            if (part == 0) hh[g][o] = hv;
+        }
+        __syncthreads();
+        // ---- Linear(H, O), criterion: 16 lanes per (graph, output): a DPP row each
+        for (int q = t / 16; q < GB * O; q += NT / 16) {
+            const int gg = q / O, o3 = q % O, l16 = t % 16;
+            const int64_t bb = b0g + gg;
+            float pv = 0.f;
+#pragma unroll
+            for (int a = l16 * (H / 16); a < (l16 + 1) * (H / 16); ++a) pv = fmaf(w3s[o3 * H + a], hh[gg][a], pv);
+            pv = group_sum<16>(pv);
+            if (l16 == 0) {
+                if (bb < B) {
+                    const float vv = pv + b3[o3];
+                    out[bb * O + o3] = vv;
+                    const float df = vv - target[bb * O + o3];
+                    const float ad = fabsf(df);
+                    float l, gq;
+                    if (ad < beta) { l = 0.5f * df * df / beta; gq = df / beta; }
+                    else           { l = ad - 0.5f * beta;      gq = df > 0.f ? 1.f : -1.f; }
+                    gq *= inv_n;
+                    grad_out[bb * O + o3] = gq;
+                    go[gg][o3] = gq;
+                    lrow[gg][o3] = l * inv_n;
+                } else {
+                    go[gg][o3] = 0.f;
+                    lrow[gg][o3] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < GB && b0g + t < B) {
+            float sl = lrow[t][0];
+            for (int o3 = 1; o3 < O; ++o3) sl += lrow[t][o3];
+            loss_rows[b0g + t] = sl;
+        }
+        if (t < GB * O) ab3p += go[t / O][t % O];
+        // ---- backward of the two Linear layers
+        {
+            float vv = 0.f;
+            for (int o3 = 0; o3 < O; ++o3) vv = fmaf(w3s[o3 * H + o], go[g][o3], vv);
+            const float g1 = bg < B ? vv * dact : 0.f;
+            if (part == 0) {
+                gh[g][o] = g1;
+                ab0p += g1;
+#pragma unroll
+                for (int o3 = 0; o3 < 8; ++o3) if (o3 < O) aw3p[o3] = fmaf(go[g][o3], hv, aw3p[o3]);       // gW3[o3, o]
+            }
+        }
+        __syncthreads();
+        {
+            float a0 = 0.f;
+            if (!HD_VAR(2)) {
+#pragma unroll
+                for (int oo = part * (H / KS); oo < (part + 1) * (H / KS); ++oo) a0 = fmaf(w0s[oo * HP + o], gh[g][oo], a0);
+            }
+            if (KS >= 2) a0 += dpp_move<0xB1>(a0);
+            if (KS >= 4) a0 += dpp_move<0x4E>(a0);
+            if (part == 0) gp[g][o] = a0;
+        }
+        if (!HD_VAR(2)) {
+#pragma unroll
+            for (int gg = 0; gg < GB; ++gg)
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    const int idx = t * PER + e;
+                    aw0[e] = fmaf(gh[gg][idx / H], pp[gg][idx % H], aw0[e]);
+                }
+        }
+        __syncthreads();
+        // ---- pool backward: my rows get gp / count, through the producer's activation when folded
+        if (cnt > 0 && !HD_VAR(1)) {
+            const float inv = 1.0f / (float)(cnt > 1 ? cnt : 1);
+            const float4 gv = make_float4(gp[gs][4 * sub] * inv, gp[gs][4 * sub + 1] * inv, gp[gs][4 * sub + 2] * inv,
+                                          gp[gs][4 * sub + 3] * inv);
+            auto back = [&](int r, float4 yy) {
+                const int64_t flat = (int64_t)(beg + r) * H + 4 * sub;
+                if (!fold) { st4(gx + flat, gv); return; }
+                uint64_t z = 0;
+                if (in_act.thr16) z = act_hash64(in_act.seed, in_stepv, (uint64_t)flat >> 2);
+                float vi[4] = {gv.x, gv.y, gv.z, gv.w};
+                const float vr[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool keep = in_act.thr16 ? (((uint32_t)(z >> (16 * c)) & 0xFFFFu) >= in_act.thr16) : true;
+                    vi[c] = vi[c] * (keep ? in_act.keep_scale : 0.f) * (vr[c] > 0.f ? 1.0f : in_act.slope);
+                }
+                const float4 o4 = make_float4(vi[0], vi[1], vi[2], vi[3]);
+                st4(gx + flat, o4);
+                acs = add4(acs, o4);
+            };
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int r = sr + SPG * k;
+                if (r < cnt) back(r, v[k]);
+            }
+            for (int r = sr + SPG * KR; r < cnt; r += SPG) back(r, fold ? ld4(x + (int64_t)(beg + r) * H + 4 * sub) : f4zero());
+        }
+    }
+    // ---- the workgroup's partial row; the per-thread sums over graphs / lane groups meet in LDS in a fixed order
+    float* part_row = partials + (int64_t)blockIdx.x * (H * H + H + O * H + O + (fold ? H : 0));
+#pragma unroll
+    for (int e = 0; e < PER; ++e) part_row[t * PER + e] = aw0[e];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(cred);          // [O + 2][256] floats: one per dense output (g, o) and array
+    if (part == 0) {
+        red[od] = ab0p;
+#pragma unroll
+        for (int o3 = 0; o3 < 8; ++o3) if (o3 < O) red[(1 + o3) * 256 + od] = aw3p[o3];
+    }
+    if (t < GB * O) red[9 * 256 + t] = ab3p;               // threads (graph, output)
+    __syncthreads();
+    if (t < H) {
+        float s2 = red[t];
+#pragma unroll
+        for (int gg = 1; gg < GB; ++gg) s2 += red[gg * H + t];
+        part_row[H * H + t] = s2;
+        for (int o3 = 0; o3 < O; ++o3) {
+            float s3 = red[(1 + o3) * 256 + t];
+#pragma unroll
+            for (int gg = 1; gg < GB; ++gg) s3 += red[(1 + o3) * 256 + gg * H + t];
+            part_row[H * H + H + o3 * H + t] = s3;
+        }
+    }
+    if (t < O) {
+        float s2 = red[9 * 256 + t];
+        for (int gg = 1; gg < GB; ++gg) s2 += red[9 * 256 + gg * O + t];
+        part_row[H * H + H + O * H + t] = s2;
+    }
+    if (fold) {
+        __syncthreads();
+        cred[t] = acs;
+        __syncthreads();
+        if (t < TPR) {
+            float4 s4 = cred[t];
+            for (int k2 = 1; k2 < RPB; ++k2) s4 = add4(s4, cred[k2 * TPR + t]);
+            st4(part_row + H * H + H + O * H + O + 4 * t, s4);
+        }
+    }
+}
+
 // out[t] = sum over the nblk workgroup partials (fixed order).  1024 threads = 64 consecutive outputs x 16 part
 // groups: every load is a 256-B row segment (the one-wave-per-output form read each partial with a stride of
 // n floats: 12.8 us for 9 MB), 8 independent loads in flight per thread, part groups meet in LDS.
@@ -522,6 +790,24 @@ extern "C" int qot_head_train(const float* x, const int32_t* ptr, const float* w
     int blocks = kHeadBwdBlocks;
     if (B < blocks) blocks = (int)B;
     const float inv_n = 1.0f / ((float)B * (float)O);
+    if (H <= 64) {
+        // the batched form: 256 / H graphs per pass, one workgroup per CU's worth of passes
+        const int gbn = 256 / H;
+        int64_t nb = (B + gbn - 1) / gbn;
+        if (nb > kHeadBwdBlocks) nb = kHeadBwdBlocks;
+        blocks = (int)nb;
+        QOT_HEAD_H(H, {
+            if constexpr (kH <= 64) {
+                const size_t lds = (size_t)(kH * (kH + 1) + 8 * kH) * sizeof(float);
+                constexpr int NT = kH * kH < kHeadThreads ? 256 : kHeadThreads;      // (H = 16: 256 entries of gW0)
+                head_train_batched_kernel<kH, NT><<<blocks, NT, lds, stream>>>(
+                    x, ptr, w0, b0, w3, b3, target, beta, inv_n, out, grad_out, loss_rows, grad_x, workspace, B, O, ap, fold,
+                    in_ap);
+            }
+        });
+        QOT_LAUNCH_CHECK();
+        return QOT_OK;
+    }
     QOT_HEAD_H(H, {
         const size_t lds = (size_t)(kHeadRowsCap * kH + kH * (kH + 1) + 8 * kH) * sizeof(float);
         static size_t allowed[kMaxDevices];                 // per device: the attribute is
@@ -533,6 +819,21 @@ extern "C" int qot_head_train(const float* x, const int32_t* ptr, const float* w
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }
+
+// workgroups (= partial rows in the workspace) of qot_head_train for B graphs at width H
+extern "C" int qot_head_train_blocks(int64_t B, int H) {
+    if (B <= 0) return 0;
+    if (H <= 64 && H >= 16) {
+        const int gbn = 256 / H;
+        const int64_t nb = (B + gbn - 1) / gbn;
+        return nb > kHeadBwdBlocks ? kHeadBwdBlocks : (int)nb;
+    }
+    return B < kHeadBwdBlocks ? (int)B : kHeadBwdBlocks;
+}
+
+#ifdef QOT_DIAG
+extern "C" void qot_debug_head_variant(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(qot::g_head_variant), &v, sizeof(int)); }
+#endif
 
 extern "C" int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const float* b0,
                                  const float* w3, const float* b3, float* pooled, float* hidden, float* out,

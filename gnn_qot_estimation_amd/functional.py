@@ -936,7 +936,7 @@ class HeadFn(torch.autograd.Function):
         nb = H * H + H + O * H + O
         grads = torch.empty(ntot, dtype=torch.float32, device=gx.device)
         loss_rows, loss_out = ctx.loss
-        roles = [(_lib.ROLE_SUM_ROWS, (ws, grads), (_lib.load().qot_head_bwd_blocks(B), ntot, 0)),
+        roles = [(_lib.ROLE_SUM_ROWS, (ws, grads), (_lib.load().qot_head_train_blocks(B, H), ntot, 0)),
                  (_lib.ROLE_SUM_ROWS, (loss_rows, loss_out), (B, 1, 0))]
         if LG.can_defer(*ctx.receivers, ctx.side.get("bias_param") if ctx.fold else None):
             for r in roles:

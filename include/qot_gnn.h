@@ -439,9 +439,11 @@ int qot_head_fwd_loss(const float* x, const int32_t* ptr, const float* w0, const
 /* The read-out of a TRAIN step in one kernel: forward + SmoothL1(mean, beta) + backward per graph (a graph's rows are read
  * once and stay in LDS for the pool backward; pooled / hidden never leave the workgroup).  grad_x[N,H] is the gradient wrt
  * the CONV output when fold != 0 (x = dropout(leaky_relu(conv)) with the in_* parameters, as qot_head_bwd(x_in)).
- * workspace: per-workgroup parameter-gradient partials [qot_head_bwd_blocks(B)][H*H + H + O*H + O (+ H when fold)] for the
- * caller to sum (QOT_ROLE_SUM_ROWS); the loss value is the sum of loss_rows[B].  Replaces {qot_head_fwd_loss, qot_head_bwd}
- * of a step (topological_training/train.py:111-115). */
+ * workspace: per-workgroup parameter-gradient partials [qot_head_train_blocks(B, H)][H*H + H + O*H + O (+ H when fold)] for
+ * the caller to sum (QOT_ROLE_SUM_ROWS); the loss value is the sum of loss_rows[B].  Replaces {qot_head_fwd_loss, qot_head_bwd}
+ * of a step (topological_training/train.py:111-115).  H <= 64 (r04): 256 / H graphs per pass of a workgroup, a graph's rows
+ * kept in registers from the pool to the pool backward (csrc/head.hip: head_train_batched_kernel). */
+int qot_head_train_blocks(int64_t B, int H);
 int qot_head_train(const float* x, const int32_t* ptr, const float* w0, const float* b0, const float* w3, const float* b3,
                    const float* target, float beta, float* out, float* grad_out, float* loss_rows, float* grad_x,
                    float* workspace, int64_t B, int H, int O, float slope, float p, uint64_t seed,
