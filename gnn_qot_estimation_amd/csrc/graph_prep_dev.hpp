@@ -40,7 +40,7 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
 // per-row ordering by edge id and the CSC mapping all happen in that workgroup's LDS -- no global
 // atomics, no cross-workgroup scan, no workspace.  Same output as the general path (same order).
 // LDS ints: cin[n] cout[n] rp[n+1] rpt[n+1] | rank_in[m] rank_out[m] key_in[m] key_out[m] slot_of[m]
-//           ends[m] (local source << 16 | local destination: the edge list is read from HBM once)
+//           ends[m] (local source << 16 | local destination: the edge list is read from HBM once) | lnid[n] (node ids)
 // status (optional): bit 0 set if an edge leaves its graph's node range (caller's slices are wrong).
 __device__ __forceinline__ void block_scan_into(const int* __restrict__ cnt, int* __restrict__ out, int n) {
     // exclusive scan of cnt[0..n) into out[0..n], out[n] = total; all 256 threads call it
@@ -81,8 +81,17 @@ __device__ __forceinline__ void csr_by_graph_body(
         if (threadIdx.x == 0 && status) atomicOr(status, 2);
         return;
     }
-    if (node_ids)
-        for (int t = threadIdx.x; t < n; t += 256) ids32[n0 + t] = (int32_t)node_ids[n0 + t];
+    // Global round trips cost ~1.5 us each here (1024 workgroups start together): the node ids and the first 512 edges are
+    // requested TOGETHER, before anything waits (first version: ids, then two edge iterations, then two more id gathers
+    // behind the sort: six trips in a row, 14 us for the job)
+    int64_t nid0 = 0;
+    if (node_ids && (int)threadIdx.x < n) nid0 = node_ids[n0 + threadIdx.x];
+    int64_t sj[2] = {0, 0}, si[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < m) { sj[u] = ei[e0 + e]; si[u] = ei[E + e0 + e]; }
+    }
     int* cin = lds;
     int* cout = cin + cap_n;
     int* rp = cout + cap_n;
@@ -93,15 +102,37 @@ __device__ __forceinline__ void csr_by_graph_body(
     int* key_out = key_in + cap_m;
     int* slot_of = key_out + cap_m;
     unsigned int* ends = reinterpret_cast<unsigned int*>(slot_of + cap_m);
+    int* lnid = reinterpret_cast<int*>(ends + cap_m);          // the graph's node ids (table mode), read back in the slot loop
     for (int t = threadIdx.x; t < n; t += 256) { cin[t] = 0; cout[t] = 0; }
+    if (node_ids) {
+        if ((int)threadIdx.x < n) { ids32[n0 + threadIdx.x] = (int32_t)nid0; lnid[threadIdx.x] = (int)nid0; }
+        for (int t = threadIdx.x + 256; t < n; t += 256) {
+            const int v = (int)node_ids[n0 + t];
+            ids32[n0 + t] = v;
+            lnid[t] = v;
+        }
+    }
     __syncthreads();
     bool bad = false;
-    for (int e = threadIdx.x; e < m; e += 256) {
-        int j = (int)(ei[e0 + e] - n0), i = (int)(ei[E + e0 + e] - n0);
-        if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
-        ends[e] = ((unsigned int)j << 16) | (unsigned int)i;
-        rank_in[e] = atomicAdd(&cin[i], 1);
-        rank_out[e] = atomicAdd(&cout[j], 1);
+    for (int ec = 0; ec < m; ec += 512) {
+        if (ec > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = ec + threadIdx.x + 256 * u;
+                if (e < m) { sj[u] = ei[e0 + e]; si[u] = ei[E + e0 + e]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = ec + threadIdx.x + 256 * u;
+            if (e < m) {
+                int j = (int)(sj[u] - n0), i = (int)(si[u] - n0);
+                if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
+                ends[e] = ((unsigned int)j << 16) | (unsigned int)i;
+                rank_in[e] = atomicAdd(&cin[i], 1);
+                rank_out[e] = atomicAdd(&cout[j], 1);
+            }
+        }
     }
     if (bad && status) atomicOr(status, 1);
     __syncthreads();
@@ -136,15 +167,17 @@ __device__ __forceinline__ void csr_by_graph_body(
     __syncthreads();
     for (int p = threadIdx.x; p < m; p += 256) {
         const int key = key_in[p];
-        const int64_t src = n0 + (int64_t)(ends[key] >> 16);
+        const int lsrc = (int)(ends[key] >> 16);
+        const int64_t src = n0 + (int64_t)lsrc;
         col[e0 + p] = (int32_t)src;
-        if (node_ids) colf[e0 + p] = (int32_t)node_ids[src];
+        if (node_ids) colf[e0 + p] = (int32_t)lnid[lsrc];
         eid[e0 + p] = (int32_t)(e0 + key);
         row[e0 + p] = (int32_t)(n0 + row_of[p]);
         const int kt = key_out[p];
-        const int64_t dst = n0 + (int64_t)(ends[kt] & 0xFFFFu);
+        const int ldst = (int)(ends[kt] & 0xFFFFu);
+        const int64_t dst = n0 + (int64_t)ldst;
         col_t[e0 + p] = (int32_t)dst;
-        if (node_ids) colf_t[e0 + p] = (int32_t)node_ids[dst];
+        if (node_ids) colf_t[e0 + p] = (int32_t)lnid[ldst];
         eid_t[e0 + p] = (int32_t)(e0 + kt);
         pos_t[e0 + p] = (int32_t)(e0 + slot_of[kt]);
     }
@@ -154,7 +187,7 @@ __device__ __forceinline__ void csr_by_graph_body(
 
 // LDS bytes of csr_by_graph_body for graphs of at most max_nodes / max_edges
 static inline size_t by_graph_lds_bytes(int64_t max_nodes, int64_t max_edges) {
-    return (size_t)(4 * max_nodes + 2 + 6 * max_edges) * 4;
+    return (size_t)(5 * max_nodes + 2 + 6 * max_edges) * 4;
 }
 constexpr size_t kByGraphLdsMax = 144 * 1024;     // one workgroup per CU at most
 constexpr int64_t kByGraphMaxNodes = 65535;       // local node ids are packed 16 + 16 bits

@@ -117,7 +117,7 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
         B = node_ptr.numel() - 1
         if (B >= 1 and edge_ptr.numel() == B + 1 and node_ptr.is_cuda and edge_ptr.is_cuda
                 and node_ptr.dtype == torch.long and edge_ptr.dtype == torch.long
-                and int(max_n) <= 65535 and (4 * int(max_n) + 2 + 6 * int(max_m)) * 4 <= 144 * 1024):
+                and int(max_n) <= 65535 and (5 * int(max_n) + 2 + 6 * int(max_m)) * 4 <= 144 * 1024):
             g.ptr32 = torch.empty(B + 1, **i32)
             ids = None
             if node_ids is not None and node_ids.is_cuda and node_ids.dtype == torch.long and node_ids.numel() == N:
