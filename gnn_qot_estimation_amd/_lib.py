@@ -122,6 +122,7 @@ SIGNATURES = {
     "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     "qot_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _p, _p, _p, _p]),
     "qot_gemm_tn_splits": (_int, [_int, _int, _i64]),
+    "qot_gemm256_takes": (_int, [_i64, _int]),
     "qot_gemm_tn_planes": (_int, [_p, _i64, _p, _i64, _p, _int, _int, _i64, _int, _p, _p, _p]),
     "qot_skinny_linear_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_skinny_linear_fwd_logits": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p]),

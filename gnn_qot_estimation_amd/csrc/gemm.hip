@@ -17,6 +17,7 @@
 // MFMAs, the ratio the fused NNConv kernels run at), operands staged through LDS in the fragment-grouped order of
 // mfma_tile.hpp (k = 8g + 2r + hi  ->  float4 slot (2g + hi) * 128 + row', component r), double buffered (64 KB: two
 // workgroups per CU), next stage prefetched into registers under the current stage's 64 MFMAs per wave.
+#include <cstdlib>
 #include "common.hpp"
 #include "mfma_tile.hpp"
 
@@ -24,16 +25,16 @@ namespace qot {
 
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
 
+#ifdef QOT_DIAG
+__device__ int g_gemm_variant;     // ablation bits of the NT kernel (tools/bench_gemm_k.py): 1 no global loads in the loop,
+#define GEMM_VAR(bit) (gemm_var & (bit))   // 2 no LDS stores, 4 no barrier, 8 no C stores, 16 no fragment reads
+#else
+#define GEMM_VAR(bit) 0
+#endif
+
 // float4 slot of (group g, k parity hi, row) inside one operand stage; the XOR spreads the four groups a quarter-wave
 // writes (NT loader) over all banks, reads of 16 consecutive rows stay a permutation of 16 consecutive slots
 __device__ __forceinline__ int gemm_slot(int g, int hi, int row) { return (2 * g + hi) * 128 + (row ^ ((g & 3) << 2)); }
-
-template <bool AFFINE>
-__device__ __forceinline__ float4 affine_relu4(float4 v, float4 s, float4 t) {
-    if (!AFFINE) return v;
-    return make_float4(fmaxf(fmaf(v.x, s.x, t.x), 0.f), fmaxf(fmaf(v.y, s.y, t.y), 0.f),
-                       fmaxf(fmaf(v.z, s.z, t.z), 0.f), fmaxf(fmaf(v.w, s.w, t.w), 0.f));
-}
 
 struct GemmFrag { float4 a[2], b[2]; };
 
@@ -64,23 +65,24 @@ __device__ __forceinline__ void gemm_group_mfma(const GemmFrag& f, f32x16 (&c)[2
 // the first fragments of the next stage have been requested: its 16 MFMAs (1024 cycles) cover that LDS round trip.
 template <class Load, class Stash>
 __device__ __forceinline__ void gemm_mainloop(float4 (&lds)[2][2][1024], int64_t nk, int wm, int wn, int hi, int r31,
-                                              f32x16 (&c)[2][2], Load load, Stash stash) {
+                                              f32x16 (&c)[2][2], Load load, Stash stash, int gemm_var = 0) {
     GemmFrag f0, f1;
     if (nk > 0) gemm_read_frag(f0, lds[0][0], lds[0][1], 0, wm, wn, hi, r31);
+    if (GEMM_VAR(16)) f1 = f0;
 #pragma unroll 1
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int cur = (int)(kt & 1);
         const bool more = kt + 1 < nk;
-        if (more) load(kt + 1);                                              // global -> registers, under the MFMAs below
-        gemm_read_frag(f1, lds[cur][0], lds[cur][1], 1, wm, wn, hi, r31);
+        if (more && !GEMM_VAR(1)) load(kt + 1);                              // global -> registers, under the MFMAs below
+        if (!GEMM_VAR(16)) gemm_read_frag(f1, lds[cur][0], lds[cur][1], 1, wm, wn, hi, r31);
         gemm_group_mfma(f0, c);
-        gemm_read_frag(f0, lds[cur][0], lds[cur][1], 2, wm, wn, hi, r31);
+        if (!GEMM_VAR(16)) gemm_read_frag(f0, lds[cur][0], lds[cur][1], 2, wm, wn, hi, r31);
         gemm_group_mfma(f1, c);
-        gemm_read_frag(f1, lds[cur][0], lds[cur][1], 3, wm, wn, hi, r31);
+        if (!GEMM_VAR(16)) gemm_read_frag(f1, lds[cur][0], lds[cur][1], 3, wm, wn, hi, r31);
         gemm_group_mfma(f0, c);
-        if (more) stash(cur ^ 1);                                            // registers -> the other LDS buffer
-        lds_barrier();
-        if (more) gemm_read_frag(f0, lds[cur ^ 1][0], lds[cur ^ 1][1], 0, wm, wn, hi, r31);
+        if (more && !GEMM_VAR(2)) stash(cur ^ 1);                            // registers -> the other LDS buffer
+        if (!GEMM_VAR(4)) lds_barrier();
+        if (more && !GEMM_VAR(16)) gemm_read_frag(f0, lds[cur ^ 1][0], lds[cur ^ 1][1], 0, wm, wn, hi, r31);
         gemm_group_mfma(f1, c);                                              // group 3 of this stage, from registers
     }
 }
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
                                                          const float* __restrict__ att_dst = nullptr,
                                                          float* __restrict__ a_src = nullptr, float* __restrict__ a_dst = nullptr) {
     __shared__ __attribute__((aligned(16))) float4 lds[2][2][1024];       // [stage][operand][slot]
+    mfma_acc_in_agprs();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2: the column tiles of ONE row block
@@ -143,48 +146,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     }
     const int64_t m0 = rb * kGemmBM;
     const int n0 = ct * kGemmBN;
-    int64_t arow[2];
-    int brow[2], gk[2];
-    bool aok[2], bok[2];
+    // rows past the end are clamped, not zeroed: row m of A only reaches row m of C (column n of B only column n), and
+    // the epilogue stores neither
+    const int gk = t & 3;                          // the k group (8 consecutive k) of both of this thread's rows
+    const float* ap[2];
+    const float* bp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pi = t + 256 * j;
-        gk[j] = pi & 3;
-        arow[j] = m0 + (pi >> 2);
-        brow[j] = n0 + (pi >> 2);
-        aok[j] = arow[j] < M;
-        bok[j] = brow[j] < N;
-        if (!aok[j]) arow[j] = M - 1;
-        if (!bok[j]) brow[j] = N - 1;
+        const int64_t ar = m0 + ((t + 256 * j) >> 2);
+        const int br = n0 + ((t + 256 * j) >> 2);
+        ap[j] = A + (ar < M ? ar : M - 1) * lda + 8 * gk;
+        bp[j] = B + (int64_t)(br < N ? br : N - 1) * ldb + 8 * gk;
     }
-    float4 pa[2][2], pb[2][2], ps[2][2], pt[2][2];
+    float4 pa[2][2], pb[2][2], ps[2], pt[2];
     auto load = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float* ap = A + arow[j] * lda + k0 + 8 * gk[j];
-            const float* bp = B + (int64_t)brow[j] * ldb + k0 + 8 * gk[j];
-            pa[j][0] = ld4(ap); pa[j][1] = ld4(ap + 4);
-            pb[j][0] = ld4(bp); pb[j][1] = ld4(bp + 4);
-            if (AFFINE) {              // requested here, applied in stash(): the loads stay in flight under the MFMAs
-                ps[j][0] = ld4(scale + k0 + 8 * gk[j]); ps[j][1] = ld4(scale + k0 + 8 * gk[j] + 4);
-                pt[j][0] = ld4(shift + k0 + 8 * gk[j]); pt[j][1] = ld4(shift + k0 + 8 * gk[j] + 4);
-            }
+            pa[j][0] = ld4(ap[j] + k0); pa[j][1] = ld4(ap[j] + k0 + 4);
+            pb[j][0] = ld4(bp[j] + k0); pb[j][1] = ld4(bp[j] + k0 + 4);
+        }
+        if (AFFINE) {                  // requested here, applied in stash(): the loads stay in flight under the MFMAs
+            ps[0] = ld4(scale + k0 + 8 * gk); ps[1] = ld4(scale + k0 + 8 * gk + 4);
+            pt[0] = ld4(shift + k0 + 8 * gk); pt[1] = ld4(shift + k0 + 8 * gk + 4);
         }
     };
+    // Fragment order of this kernel: MFMA r of group g multiplies the k pair {8g + r, 8g + 4 + r} (the hi = 0 lanes
+    // supply the first, the hi = 1 lanes the second; A and B agree, which is all the product needs), so the float4 a
+    // lane feeds to four consecutive MFMAs is four CONSECUTIVE k of its row: the 16-byte pieces go from the global load
+    // to LDS as they are (the interleaved order of mfma_tile.hpp cost 52 register moves per stage here, and on this part
+    // every VALU instruction is an MFMA issue slot lost).
     auto stash = [&](int s) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int row = (t + 256 * j) >> 2, g = gk[j];
+            const int row = (t + 256 * j) >> 2;
             if (AFFINE) {
-                pa[j][0] = affine_relu4<true>(pa[j][0], ps[j][0], pt[j][0]);
-                pa[j][1] = affine_relu4<true>(pa[j][1], ps[j][1], pt[j][1]);
+                pa[j][0] = affine_relu4<true>(pa[j][0], ps[0], pt[0]);
+                pa[j][1] = affine_relu4<true>(pa[j][1], ps[1], pt[1]);
             }
-            if (!aok[j]) { pa[j][0] = f4zero(); pa[j][1] = f4zero(); }
-            if (!bok[j]) { pb[j][0] = f4zero(); pb[j][1] = f4zero(); }
-            lds[s][0][gemm_slot(g, 0, row)] = make_float4(pa[j][0].x, pa[j][0].z, pa[j][1].x, pa[j][1].z);
-            lds[s][0][gemm_slot(g, 1, row)] = make_float4(pa[j][0].y, pa[j][0].w, pa[j][1].y, pa[j][1].w);
-            lds[s][1][gemm_slot(g, 0, row)] = make_float4(pb[j][0].x, pb[j][0].z, pb[j][1].x, pb[j][1].z);
-            lds[s][1][gemm_slot(g, 1, row)] = make_float4(pb[j][0].y, pb[j][0].w, pb[j][1].y, pb[j][1].w);
+            lds[s][0][gemm_slot(gk, 0, row)] = pa[j][0];
+            lds[s][0][gemm_slot(gk, 1, row)] = pa[j][1];
+            lds[s][1][gemm_slot(gk, 0, row)] = pb[j][0];
+            lds[s][1][gemm_slot(gk, 1, row)] = pb[j][1];
         }
     };
     f32x16 c[2][2];
@@ -198,7 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     load(0);
     stash(0);
     __syncthreads();
-    gemm_mainloop(lds, nk, wm, wn, hi, r31, c, [&](int64_t kt) { load((int)kt * kGemmBK); }, stash);
+#ifdef QOT_DIAG
+    const int gemm_var = g_gemm_variant;
+#else
+    const int gemm_var = 0;
+#endif
+    gemm_mainloop(lds, nk, wm, wn, hi, r31, c, [&](int64_t kt) { load((int)kt * kGemmBK); }, stash, gemm_var);
     // epilogue through LDS: tile row p = output row m0 + p, tile column q = output column n0 + q
     float* tile = reinterpret_cast<float*>(&lds[0][0][0]);
     gemm_tile_to_lds(tile, c, wm, wn, hi, r31);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
         if (row < M && col < N) {
             float4 v = ld4(tile + pm * 128 + ((4 * q4) ^ ((pm & 7) << 2)));
             if (bias) { const float4 bz = ld4(bias + col); v = add4(v, bz); }
-            st4(C + row * ldc + col, v);
+            if (!GEMM_VAR(8) || v.x == 12345.678f) st4(C + row * ldc + col, v);
         }
     }
     if (LOGITS) {
@@ -239,17 +246,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
 }
 
 // ---- TN: both operands [K, rows] (row index = k), split-K over gridDim.z ---------------------------------------
-// threads 0..127 stage A, 128..255 stage B: thread u owns (quad q = u % 32, group g = u / 32): eight k rows x four
-// consecutive output rows (one float4 per k row: a wave reads 512 contiguous bytes per k row), transposed in registers
-// into the fragment order.  Output row 4q + c is kept at tile row c*32 + q (writes of a quarter-wave then fall on 16
-// consecutive slots); the epilogue undoes the permutation.
+// The operands arrive with the OUTPUT index contiguous, the opposite of what a float4 fragment wants.  Rounds 3's kernel
+// transposed 8 x 4 blocks in registers on the way to LDS (32 moves + 32 selects per thread and stage, every one an MFMA
+// issue slot lost).  Here the stage keeps the global order -- T[k][c], 32 k rows of 128 floats, 16-byte pieces stored as
+// loaded -- and the MFMA operands are read one dword per MFMA, two at a time:
+//   MFMA 2p / 2p + 1 of a stage multiply the k pairs {4p, 4p + 2} / {4p + 1, 4p + 3}: lane (hi, r) reads rows
+//   4p + 2hi and 4p + 2hi + 1 of its column with ONE ds_read2_b32 (second address + 128 dwords);
+//   column c of row k sits at dword c ^ (32 * ((k >> 1) & 1)), so the hi = 0 and hi = 1 halves of a wave fall on
+//   disjoint bank halves: no conflicts on either side (a quarter-wave writes 256 contiguous bytes).
+// Every thread stages four k rows of BOTH operands (thread t: quad q = t % 32 of the tile's 128 columns, rows 4 (t / 32)
+// + s), so the BatchNorm/ReLU prologue of the B operand is spread over all four waves.
+__device__ __forceinline__ int tn_dword(int k, int c) { return k * 128 + (c ^ (((k >> 1) & 1) << 5)); }
+
+struct TnFrag { float a[2][2], b[2][2]; };       // [tile][MFMA of the pair]
+
+__device__ __forceinline__ void tn_read_frag(TnFrag& f, const float* __restrict__ As, const float* __restrict__ Bs, int p,
+                                             int wm, int wn, int hi, int r31) {
+    const int k = 4 * p + 2 * hi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* s = As + tn_dword(k, wm * 64 + i * 32 + r31);
+        f.a[i][0] = s[0];
+        f.a[i][1] = s[128];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* s = Bs + tn_dword(k, wn * 64 + j * 32 + r31);
+        f.b[j][0] = s[0];
+        f.b[j][1] = s[128];
+    }
+}
+
+__device__ __forceinline__ void tn_pair_mfma(const TnFrag& f, f32x16 (&c)[2][2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][u], f.b[0][u], c[0][0], 0, 0, 0);
+        c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][u], f.b[1][u], c[0][1], 0, 0, 0);
+        c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][u], f.b[0][u], c[1][0], 0, 0, 0);
+        c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[1][u], f.b[1][u], c[1][1], 0, 0, 0);
+    }
+}
+
 template <bool AFFINE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ Cpart, int M, int N, int64_t K,
                                                                int64_t kchunk, int nsplit, const float* __restrict__ scale,
                                                                const float* __restrict__ shift) {
-    __shared__ __attribute__((aligned(16))) float4 lds[2][2][1024];
+    __shared__ __attribute__((aligned(16))) float lds[2][2][32 * 128];     // [stage][operand][k][column']
+    mfma_acc_in_agprs();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
     // all output tiles of ONE split (they share its K chunk of both operands) on ONE XCD (id % 8), back to back
@@ -272,39 +317,58 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
     const int m0 = (tile_id / ntn) * kGemmBM, n0 = (tile_id % ntn) * kGemmBN;
     const int64_t kbeg = (int64_t)split * kchunk;
     const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    const bool isb = t >= 128;
-    const int u = t & 127, q = u & 31, g = u >> 5;
-    const float* src = isb ? B : A;
-    const int64_t ld = isb ? ldb : lda;
-    const int c0 = (isb ? n0 : m0) + 4 * q;
-    const int lim = isb ? N : M;
-    const bool cok = c0 + 3 < lim;                 // M, N multiples of 4 (checked by the host side)
+    const int q = t & 31, kr = 4 * (t >> 5);             // column quad, first of my four k rows inside a stage
+    // columns past the end are clamped, not zeroed (column m of A only reaches row m of C; the epilogue skips it);
+    // M, N multiples of 4 (checked by the host side)
+    const int ca = (m0 + 4 * q + 3 < M) ? m0 + 4 * q : M - 4;
+    const int cb = (n0 + 4 * q + 3 < N) ? n0 + 4 * q : N - 4;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-    if (AFFINE && isb && cok) { sc = ld4(scale + c0); sh = ld4(shift + c0); }
-    float4 pv[8];
+    if (AFFINE) { sc = ld4(scale + cb); sh = ld4(shift + cb); }
+    float4 pa[4], pb[4];
+    uint32_t oa[4], ob[4];                               // (kr + s) * ld + column: < 2^32 (checked by the host side)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        oa[s] = (uint32_t)((kr + s) * lda + ca);
+        ob[s] = (uint32_t)((kr + s) * ldb + cb);
+    }
     int64_t pk0 = 0;
     auto load = [&](int64_t k0) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int64_t k = k0 + 8 * g + s;
-            const bool ok = cok && k < kend;
-            pv[s] = ld4(src + (ok ? k : kbeg) * ld + (cok ? c0 : 0));
-        }
         pk0 = k0;
+        if (k0 + kGemmBK <= kend) {                      // uniform: all but the last stage of a ragged chunk
+            // uniform base (scalar registers, advanced by the scalar unit) + per-thread 32-bit offsets that never
+            // change: no vector address arithmetic in the loop
+            const float* a = A + k0 * lda;
+            const float* b = B + k0 * ldb;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                pa[s] = ld4(a + oa[s]);
+                pb[s] = ld4(b + ob[s]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int64_t k = (k0 + kr + s < kend) ? k0 + kr + s : kend - 1;
+                pa[s] = ld4(A + k * lda + ca);
+                pb[s] = ld4(B + k * ldb + cb);
+            }
+        }
     };
     auto stash = [&](int st) {
-        float4* dst = lds[st][isb ? 1 : 0];
-        // transform / zero what was loaded (not in load(): a use right behind a load keeps only that load in flight)
+        // transform what was loaded (not in load(): a use right behind a load keeps only that load in flight)
+        if (AFFINE) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (AFFINE && isb) pv[s] = affine_relu4<true>(pv[s], sc, sh);
-            if (!(cok && pk0 + 8 * g + s < kend)) pv[s] = f4zero();
+            for (int s = 0; s < 4; ++s) pb[s] = affine_relu4<true>(pb[s], sc, sh);
         }
-#define QOT_T(COMP, CI)                                                                                      \
-        dst[gemm_slot(g, 0, (CI) * 32 + q)] = make_float4(pv[0].COMP, pv[2].COMP, pv[4].COMP, pv[6].COMP);   \
-        dst[gemm_slot(g, 1, (CI) * 32 + q)] = make_float4(pv[1].COMP, pv[3].COMP, pv[5].COMP, pv[7].COMP);
-        QOT_T(x, 0) QOT_T(y, 1) QOT_T(z, 2) QOT_T(w, 3)
-#undef QOT_T
+        if (pk0 + kGemmBK > kend) {                      // rows past the chunk contribute nothing: zero BOTH operands' copies
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (pk0 + kr + s >= kend) { pa[s] = f4zero(); pb[s] = f4zero(); }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st4(&lds[st][0][tn_dword(kr + s, 4 * q)], pa[s]);
+            st4(&lds[st][1][tn_dword(kr + s, 4 * q)], pb[s]);
+        }
     };
     f32x16 c[2][2];
 #pragma unroll
@@ -319,34 +383,58 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
         stash(0);
     }
     __syncthreads();
-    gemm_mainloop(lds, nk, wm, wn, hi, r31, c, [&](int64_t kt) { load(kbeg + kt * kGemmBK); }, stash);
+    // stages of 8 k quads (8 MFMAs per wave each); fragments one quad ahead, the next stage's LDS stores between the
+    // quads, the last quad multiplied behind the barrier (same schedule as gemm_mainloop)
+    TnFrag f0, f1;
+    if (nk > 0) tn_read_frag(f0, lds[0][0], lds[0][1], 0, wm, wn, hi, r31);
+#pragma unroll 1
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        const bool more = kt + 1 < nk;
+        if (more) load(kbeg + (kt + 1) * kGemmBK);
+#pragma unroll
+        for (int p = 0; p < 6; p += 2) {
+            tn_read_frag(f1, lds[cur][0], lds[cur][1], p + 1, wm, wn, hi, r31);
+            tn_pair_mfma(f0, c);
+            tn_read_frag(f0, lds[cur][0], lds[cur][1], p + 2, wm, wn, hi, r31);
+            tn_pair_mfma(f1, c);
+        }
+        tn_read_frag(f1, lds[cur][0], lds[cur][1], 7, wm, wn, hi, r31);
+        tn_pair_mfma(f0, c);
+        if (more) stash(cur ^ 1);
+        lds_barrier();
+        if (more) tn_read_frag(f0, lds[cur ^ 1][0], lds[cur ^ 1][1], 0, wm, wn, hi, r31);
+        tn_pair_mfma(f1, c);
+    }
     float* Cp = Cpart + (int64_t)split * M * N;
-    // epilogue through LDS; tile row p = c*32 + q holds output row 4q + c (columns likewise)
-    float* tile = reinterpret_cast<float*>(&lds[0][0][0]);
+    // epilogue through LDS: tile row p = output row m0 + p, tile column q = output column n0 + q
+    float* tile = &lds[0][0][0];
     gemm_tile_to_lds(tile, c, wm, wn, hi, r31);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
-        const int idx = it * 256 + t;                 // output-ordered float4: local row ro = idx / 32, quad qo = idx % 32
-        const int ro = idx >> 5, qo = idx & 31;
-        const int pm = (ro & 3) * 32 + (ro >> 2);     // tile row of output row ro
-        const int row = m0 + ro, col = n0 + 4 * qo;
-        if (row < M && col < N) {
-            // output columns 4qo + cc live at tile columns cc*32 + qo
-            float v[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int pn = cc * 32 + qo;
-                v[cc] = tile[pm * 128 + (pn ^ ((pm & 7) << 2))];
-            }
-            st4(Cp + (int64_t)row * N + col, make_float4(v[0], v[1], v[2], v[3]));
-        }
+        const int idx = it * 256 + t;                 // float4 index: row = idx / 32, quad = idx % 32
+        const int pm = idx >> 5, q4 = idx & 31;
+        const int row = m0 + pm, col = n0 + 4 * q4;
+        if (row < M && col < N) st4(Cp + (int64_t)row * N + col, ld4(tile + pm * 128 + ((4 * q4) ^ ((pm & 7) << 2))));
     }
 }
 
 }  // namespace qot
 
 using namespace qot;
+
+// gemm256.hip: the 256 x 256 forms for large M
+extern "C" int qot_gemm256_takes(int64_t M, int N);
+int gemm256_nt_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                      const float* scale, const float* shift, const float* bias, const float* att_src, const float* att_dst,
+                      float* a_src, float* a_dst, hipStream_t stream);
+
+#ifdef QOT_DIAG
+extern "C" int qot_debug_gemm_variant(int v) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(qot::g_gemm_variant), &v, sizeof(int)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // C[M, N] = A'[M, K] . B[N, K]^T (+ bias[N]);  A' = relu(A * scale[k] + shift[k]) when scale != NULL.
 // K multiple of 32, lda / ldb multiples of 4, 16-byte aligned operands.
@@ -358,6 +446,9 @@ extern "C" int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t 
     if ((K % kGemmBK) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
         ((uintptr_t)C & 15) || ((uintptr_t)bias & 15))
         return QOT_ERR_UNSUPPORTED;
+    if (qot_gemm256_takes(M, N))
+        return gemm256_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias, nullptr, nullptr, nullptr, nullptr,
+                                 (hipStream_t)stream);
     const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
     if (tiles > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
     if (scale)
@@ -380,6 +471,9 @@ extern "C" int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, i
     if ((K % kGemmBK) || (N % kGemmBN) || (lda & 3) || (ldb & 3) || (ldc & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
         ((uintptr_t)C & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)att_src & 15) || ((uintptr_t)att_dst & 15))
         return QOT_ERR_UNSUPPORTED;
+    if (qot_gemm256_takes(M, N) && N <= 1024)
+        return gemm256_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias, att_src, att_dst, a_src, a_dst,
+                                 (hipStream_t)stream);
     const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * (N / kGemmBN);
     if (tiles > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
     if (scale)
@@ -410,7 +504,8 @@ extern "C" int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, i
                                   int64_t K, int splits, const float* scale, const float* shift, qot_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || splits <= 0) return QOT_ERR_BADARG;
     if (!A || !B || !Cpart || (scale && !shift)) return QOT_ERR_BADARG;
-    if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)Cpart & 15))
+    if ((M & 3) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)Cpart & 15) ||
+        lda < M || ldb < N || lda > (1 << 24) || ldb > (1 << 24))      // a stage's 32 rows are addressed with 32-bit offsets
         return QOT_ERR_UNSUPPORTED;
     int64_t kchunk = (K + splits - 1) / splits;
     kchunk = (kchunk + kGemmBK - 1) / kGemmBK * kGemmBK;

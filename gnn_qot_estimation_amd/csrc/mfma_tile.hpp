@@ -26,6 +26,25 @@ __device__ __forceinline__ f32x16 mfma_group(const float4* __restrict__ At4, int
     return c;
 }
 
+// Accumulators in AGPRs.  At <= 256 registers per lane and no other AGPR use the compiler selects the MFMAs' VGPR form
+// (dst / srcC in the architectural file); one inline-asm operand with an "a" constraint makes it select the AGPR form for
+// the whole kernel: the accumulator traffic of the matrix pipe then stays off the ports the LDS / global load returns and
+// the VALU use (measured in gemm.hip, tools/bench_gemm_k.py).  Call once at the top of a kernel.
+__device__ __forceinline__ void mfma_acc_in_agprs() {
+#ifndef QOT_NO_AGPR_HINT
+    float az = 0.f;
+    asm volatile("; accumulators in AGPRs" : "+a"(az));
+#endif
+}
+
+// relu(v * s + t): BatchNorm(+ReLU) of the previous layer applied while a GEMM operand is loaded (gemm.hip, gemm256.hip)
+template <bool AFFINE>
+__device__ __forceinline__ float4 affine_relu4(float4 v, float4 s, float4 t) {
+    if (!AFFINE) return v;
+    return make_float4(fmaxf(fmaf(v.x, s.x, t.x), 0.f), fmaxf(fmaf(v.y, s.y, t.y), 0.f),
+                       fmaxf(fmaf(v.z, s.z, t.z), 0.f), fmaxf(fmaf(v.w, s.w, t.w), 0.f));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits vmcnt(0), i.e. it
 // drains the epilogue's global stores (measured: ~30 % of the tile time went there).
 __device__ __forceinline__ void lds_barrier() {

@@ -1263,23 +1263,44 @@ def skinny_ok(f: int, c: int) -> bool:
     return 1 <= f <= 8 and c % 4 == 0 and 4 <= c <= 1024 and (256 // (c // 4)) * c * f * 4 <= 64 * 1024
 
 
+def gemm_nt_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """``a @ b.T`` fits ``qot_gemm_nt`` (``a [M, K]``, ``b [N, K]``)."""
+    return a.is_cuda and a.dtype == torch.float32 and gemm_ok(a.shape[1], b.shape[0])
+
+
+def _library_gemm() -> bool:
+    """``QOT_LIBRARY_GEMM=1``: the large projections' forward / grad_x products through the BLAS library instead of
+    ``qot_gemm_nt`` (comparison runs; ``tools/bench_gemm.py`` has both at cfg3's shape)."""
+    return bool(os.environ.get("QOT_LIBRARY_GEMM"))
+
+
+def grad_x_product(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """``g @ W`` ([N, out] x [out, in]) as ``qot_gemm_nt(g, W^T)``: the weight is small (<= 1 MB), its transpose one
+    tiny copy, and both operands of the product are then k-contiguous."""
+    if _library_gemm() or not gemm_nt_ok(g, weight.t()):
+        return g @ weight
+    return gemm_nt(g, weight.t().contiguous())
+
+
 class GemmFn(torch.autograd.Function):
-    """``x @ W^T`` (no bias) for GATConv's projection.  Forward and grad_x go to the library (measured at cfg3's shape,
-    ``tools/bench_gemm.py``: 135 TFLOP/s there against 110 for ``qot_gemm_nt``); the weight gradient ``g^T x`` -- inner
-    dimension = number of nodes, the shape the library runs at 98 TFLOP/s -- goes to ``qot_gemm_tn_planes`` (109)."""
+    """``x @ W^T`` (no bias) for GATConv's projection: forward and grad_x on ``qot_gemm_nt`` (256 x 256 tiles at cfg3's
+    shape, ``csrc/gemm256.hip``), the weight gradient ``g^T x`` -- inner dimension = number of nodes -- on
+    ``qot_gemm_tn_planes``."""
 
     @staticmethod
     def forward(ctx, x, weight):
         require_cuda(x, weight)
         x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
-        return x @ weight.t()
+        if _library_gemm() or not gemm_nt_ok(x, weight):
+            return x @ weight.t()
+        return gemm_nt(x, weight)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = _f32c(g)
-        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gx = grad_x_product(g, weight) if ctx.needs_input_grad[0] else None
         return gx, gemm_tn_planes(g, x)
 
 
@@ -1324,7 +1345,7 @@ class BnLinearFn(torch.autograd.Function):
         if N == 0:
             return (torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(bias), None, None, None, None, None,
                     None, None, torch.zeros_like(lin_weight), None, None)
-        gy = gz @ lin_weight                                 # [N, C]: the library's product (135 vs 122 TFLOP/s)
+        gy = grad_x_product(gz, lin_weight)                  # [N, C]
         g_lin = gemm_tn_planes(gz, x, scale, shift)          # [out, C] = gz^T relu(bn(x))
         gx, gw, gb = _bn_backward(gy, x, bias, mean, rstd, weight, n_tot, training, True, synced)
         return gx, gw, gb, None, None, None, None, None, None, None, g_lin, None, None

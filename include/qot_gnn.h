@@ -509,6 +509,10 @@ int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, int64_t ldb,
                        const float* scale, const float* shift, const float* bias, const float* att_src,
                        const float* att_dst, float* a_src, float* a_dst, qot_stream_t stream);
 int qot_gemm_tn_splits(int M, int N, int64_t K);
+/* 1 when qot_gemm_nt / qot_gemm_nt_logits run a product of this size on the 256 x 256 x 32 tiles of csrc/gemm256.hip (one
+ * persistent workgroup per CU; at least one tile per CU and N >= 256), 0 for the 128 x 128 tiles of csrc/gemm.hip.  Same
+ * results either way up to the order of the K sum inside a tile; for tests and tools. */
+int qot_gemm256_takes(int64_t M, int N);
 int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int M, int N, int64_t K,
                        int splits, const float* scale, const float* shift, qot_stream_t stream);
 

@@ -10,12 +10,15 @@ def _rel(a, ref):
     return float((a.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (128, 128, 32), (77, 512, 64), (4099, 128, 512), (1, 32, 32)])
+# the last three sizes run on the 256 x 256 tiles of gemm256.hip (>= one tile per CU): ragged M, ragged N, two stages
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (128, 128, 32), (77, 512, 64), (4099, 128, 512), (1, 32, 32),
+                                   (33003, 512, 64), (66010, 260, 96), (40000, 512, 32)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_gemm_nt_matches_fp64(cuda_device, M, N, K, affine):
     from gnn_qot_estimation_amd import _lib
     torch.manual_seed(0)
     dev = cuda_device
+    assert _lib.load().qot_gemm256_takes(M, N) == (1 if M > 30000 else 0)
     A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
     bias = torch.randn(N, device=dev)
     scale, shift = (torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)) if affine else (None, None)
@@ -32,7 +35,9 @@ def test_gemm_nt_matches_fp64(cuda_device, M, N, K, affine):
     assert bool(torch.isnan(Cw[:, N:]).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (128, 512, 33), (512, 128, 100000), (4, 8, 7)])
+# the last two: ragged chunk ends, ragged M / N at a long K
+@pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (128, 512, 33), (512, 128, 100000), (4, 8, 7), (512, 512, 70001),
+                                   (260, 388, 66000)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_gemm_tn_planes_sum_to_the_product(cuda_device, M, N, K, affine):
     from gnn_qot_estimation_amd import _lib
@@ -115,7 +120,7 @@ def test_skinny_first_layer_projection_and_weight_gradient(cuda_device, N, F, C)
     assert torch.equal(g1, w.grad)
 
 
-@pytest.mark.parametrize("M,heads,K", [(1000, 4, 512), (77, 1, 64), (4099, 2, 128)])
+@pytest.mark.parametrize("M,heads,K", [(1000, 4, 512), (77, 1, 64), (4099, 2, 128), (33003, 4, 64), (70001, 3, 32)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_gemm_nt_logits_epilogue_matches_fp64(cuda_device, M, heads, K, affine):
     """qot_gemm_nt_logits: the product and GATConv's attention logits a[m, h] = <out[m, h, :], att[h, :]> (128 channels per
