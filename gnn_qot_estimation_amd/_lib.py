@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 8          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 9          # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -95,6 +95,9 @@ SIGNATURES = {
     "qot_bn_apply": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_bn_bwd_reduce": (_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p, _p, _p]),
     "qot_bn_bwd_apply": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _p, _p]),
+    "qot_bn_apply_rows": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _int, _int, _p]),
+    "qot_bn_bwd_reduce_rows": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _int, _int, _p, _p, _p, _p]),
+    "qot_bn_bwd_apply_rows": (_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _p, _p]),
     "qot_sgd_momentum": (_int, [_p, _p, _p, _i64, _f, _f, _int, _p]),
     "qot_sgd_momentum_multi": (_int, [_p, _p, _p, _int, _p, _p, _i64, _f, _p, _f, _int, _p]),
     "qot_sgd_momentum_dev": (_int, [_p, _p, _p, _i64, _p, _f, _int, _p]),

@@ -151,7 +151,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partials,
-    int64_t N, int C, int relu, const float* __restrict__ wgt, const float* __restrict__ bia) {
+    int64_t N, int C, int relu, const float* __restrict__ wgt, const float* __restrict__ bia,
+    const int32_t* __restrict__ rows = nullptr) {
+    // rows != NULL (MODE 1): dy is [N, C] compact and its row r belongs to row rows[r] of x (qot_bn_bwd_reduce_rows)
     // relu with y == NULL: the mask is recomputed from x with the forward's own expression (bn_apply_kernel) -- one
     // [N, C] read fewer than taking it from the saved output
     __shared__ float4 r1[256];
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
         if (MODE == 0) sh = ld4(x + c);
         else { mu = ld4(mean + c); rs = ld4(rstd + c); if (relu && !y) { wv = ld4(wgt + c); bv = ld4(bia + c); } }
         for (int64_t r = r0 + slot; r < r1e; r += RPB) {
-            float4 xv = ld4(x + r * C + c);
+            float4 xv = ld4(x + ((MODE == 1 && rows) ? (int64_t)rows[r] : r) * C + c);
             if (MODE == 0) {
                 float4 d = sub4(xv, sh);
                 s1 = add4(s1, d);
@@ -294,11 +296,12 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ partials, int n
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, const float* __restrict__ w,
                                 const float* __restrict__ b, float* __restrict__ y, int64_t N, int C4,
-                                int relu) {
+                                int relu, const int32_t* __restrict__ rows = nullptr) {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= N * C4) return;
     int c = (int)(t % C4) * 4;
-    float4 xv = ld4(x + 4 * t), mu = ld4(mean + c), rs = ld4(rstd + c), wv = ld4(w + c), bv = ld4(b + c);
+    const int64_t xt = rows ? (int64_t)rows[t / C4] * C4 + t % C4 : t;     // rows: y is compact, its row r = row rows[r] of x
+    float4 xv = ld4(x + 4 * xt), mu = ld4(mean + c), rs = ld4(rstd + c), wv = ld4(w + c), bv = ld4(b + c);
     float4 o = make_float4(fmaf((xv.x - mu.x) * rs.x, wv.x, bv.x), fmaf((xv.y - mu.y) * rs.y, wv.y, bv.y),
                            fmaf((xv.z - mu.z) * rs.z, wv.z, bv.z), fmaf((xv.w - mu.w) * rs.w, wv.w, bv.w));
     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -310,15 +313,20 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ rstd, const float* __restrict__ w,
                                     const float* __restrict__ gw, const float* __restrict__ gb,
                                     float* __restrict__ gx, int64_t N, int C4, int relu, int batch_stats,
-                                    const float* __restrict__ bia) {
+                                    const float* __restrict__ bia, const int32_t* __restrict__ rows = nullptr,
+                                    int64_t n_total = 0) {
+    // rows form (qot_bn_bwd_apply_rows): dy is compact [N, C] and belongs to rows rows[r] of x / gx, the batch has
+    // n_total rows; dy == NULL: the rows whose dy is zero (same expression, so both forms give the dense form's bits)
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= N * C4) return;
     int c = (int)(t % C4) * 4;
-    float4 g = ld4(dy + 4 * t);
+    const int64_t xt = rows ? (int64_t)rows[t / C4] * C4 + t % C4 : t;
+    if (!rows) n_total = N;
+    float4 g = dy ? ld4(dy + 4 * t) : f4zero();
     float4 rs = ld4(rstd + c), wv = ld4(w + c);
     float4 xv = f4zero(), mu = f4zero();
-    if (batch_stats || (relu && !y)) { xv = ld4(x + 4 * t); mu = ld4(mean + c); }
-    if (relu) {
+    if (batch_stats || (relu && !y)) { xv = ld4(x + 4 * xt); mu = ld4(mean + c); }
+    if (relu && dy) {
         float4 yv;
         if (y) yv = ld4(y + 4 * t);
         else {      // the forward's own expression (bn_apply_kernel): same mask, one [N, C] read fewer
@@ -331,7 +339,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     float4 o;
     if (batch_stats) {
         float4 a = ld4(gw + c), b = ld4(gb + c);
-        const float in = 1.0f / (float)N;
+        const float in = 1.0f / (float)n_total;
         o.x = wv.x * rs.x * (g.x - b.x * in - (xv.x - mu.x) * rs.x * a.x * in);
         o.y = wv.y * rs.y * (g.y - b.y * in - (xv.y - mu.y) * rs.y * a.y * in);
         o.z = wv.z * rs.z * (g.z - b.z * in - (xv.z - mu.z) * rs.z * a.z * in);
@@ -339,7 +347,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     } else {
         o = make_float4(g.x * wv.x * rs.x, g.y * wv.y * rs.y, g.z * wv.z * rs.z, g.w * wv.w * rs.w);
     }
-    st4(gx + 4 * t, o);
+    st4(gx + 4 * xt, o);
 }
 
 // ----------------------------------------------------------------------------- optimizer / reductions
@@ -840,6 +848,61 @@ extern "C" int qot_bn_bwd_apply(const float* grad_y, const float* y, const float
     bn_bwd_apply_kernel<<<grid_for(N * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(
         grad_y, y, x, mean, rstd, w, gw, gb, grad_x, N, C / 4, relu, batch_stats, b);
     QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// ---- BatchNorm(+ReLU) of which only some rows are consumed: y_rows = act(BatchNorm(x))[idx] (LightpathGNN's LUT rows,
+// lightpath_training/models.py:31-32 then :35-40).  The statistics are those of all N rows (computed elsewhere); the
+// normalised matrix is never formed, the backward's column sums run over the n rows that carry a gradient, and grad_x
+// (dense: every row feels the batch statistics) is written without a zero-filled [N, C] gradient being read.
+// idx: n unique row numbers.
+extern "C" int qot_bn_apply_rows(const float* x, const int32_t* idx, int64_t n, const float* mean, const float* rstd,
+                                 const float* w, const float* b, float* y_rows, int C, int relu, qot_stream_t stream) {
+    if (n < 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (n == 0) return QOT_OK;
+    if (!x || !idx || !mean || !rstd || !w || !b || !y_rows) return QOT_ERR_BADARG;
+    bn_apply_kernel<<<grid_for(n * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(x, mean, rstd, w, b, y_rows, n, C / 4, relu, idx);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// gb[c] = sum_r dy'[r, c], gw[c] = sum_r dy'[r, c] * xhat[idx[r], c]  (dy' = dy * [y > 0] when relu; mask recomputed
+// from x);  partials: qot_bn_partials_floats(n, C) floats.
+extern "C" int qot_bn_bwd_reduce_rows(const float* grad_rows, const int32_t* idx, int64_t n, const float* x,
+                                      const float* mean, const float* rstd, float* gw, float* gb, int C, int relu,
+                                      float* partials, const float* w, const float* b, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0 || C > 1024) return QOT_ERR_UNSUPPORTED;
+    if (!grad_rows || !idx || !x || !mean || !rstd || !gw || !gb || !partials || (relu && (!w || !b))) return QOT_ERR_BADARG;
+    int nblk = bn_blocks(n);
+    bn_partial_kernel<1><<<nblk, 256, 0, stream>>>(x, grad_rows, nullptr, mean, rstd, partials, n, C, relu, w, b, idx);
+    QOT_LAUNCH_CHECK();
+    bn_finalize_bwd_kernel<<<grid_for(C, 4), 256, 0, stream>>>(partials, nblk, C, gw, gb);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// grad_x [N, C] of the batch-statistics form: every row from (gw, gb) and x alone, then the n rows of idx again with
+// their gradient -- bit for bit qot_bn_bwd_apply on the zero-filled, scattered [N, C] gradient.
+extern "C" int qot_bn_bwd_apply_rows(const float* grad_rows, const int32_t* idx, int64_t n, const float* x,
+                                     const float* mean, const float* rstd, const float* w, const float* gw,
+                                     const float* gb, float* grad_x, int64_t N, int C, int relu, const float* b,
+                                     qot_stream_t stream) {
+    if (N < 0 || n < 0 || n > N) return QOT_ERR_BADARG;
+    if ((C & 3) || C <= 0) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!x || !mean || !rstd || !w || !gw || !gb || !grad_x || (n > 0 && (!grad_rows || !idx)) || (relu && !b))
+        return QOT_ERR_BADARG;
+    bn_bwd_apply_kernel<<<grid_for(N * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        nullptr, nullptr, x, mean, rstd, w, gw, gb, grad_x, N, C / 4, relu, 1, b);
+    QOT_LAUNCH_CHECK();
+    if (n > 0) {
+        bn_bwd_apply_kernel<<<grid_for(n * (C / 4), 256), 256, 0, (hipStream_t)stream>>>(
+            grad_rows, nullptr, x, mean, rstd, w, gw, gb, grad_x, n, C / 4, relu, 1, b, idx, N);
+        QOT_LAUNCH_CHECK();
+    }
     return QOT_OK;
 }
 

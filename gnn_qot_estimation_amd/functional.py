@@ -167,7 +167,18 @@ class SmallLinearFn(torch.autograd.Function):
         if ctx.big:
             return (g @ weight if ctx.needs_input_grad[0] else None), g.t() @ x, colsum(g)
         gx = _small_gemm(g, weight, None, m, k, n, n, 1, k, 1) if ctx.needs_input_grad[0] else None   # g @ W
-        gw = _small_gemm(g, x, None, n, k, m, 1, n, k, 1)                  # g^T @ x: A(i,r) = g[r,i]
+        if m >= 4096 and skinny_ok(n, k):
+            # a handful of outputs over many rows (LightpathGNN's last Linear: 65 536 LUT rows x 128 -> 1): g^T x is the
+            # skinny weight gradient with the operands' roles swapped, (x^T g)[k, n] = gw[n, k]^T -- row-parallel partial
+            # sums in a fixed order instead of 16 workgroups walking 4096 rows each (394 -> ~10 us at cfg3)
+            nblk = _lib.load().qot_skinny_linear_dw_blocks(m)
+            part = torch.empty(nblk, k * n, dtype=torch.float32, device=g.device)
+            _lib.call("qot_skinny_linear_dw", P(x), P(g), P(part), m, n, k)
+            gwt = torch.empty(k * n, dtype=torch.float32, device=g.device)
+            _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, gwt), (nblk, k * n, 0))])
+            gw = gwt.view(k, n).t().contiguous() if n > 1 else gwt.view(1, k)
+        else:
+            gw = _small_gemm(g, x, None, n, k, m, 1, n, k, 1)              # g^T @ x: A(i,r) = g[r,i]
         return gx, gw, colsum(g) if m >= 64 else g.sum(0)
 
 
@@ -1147,6 +1158,65 @@ class BnFn(torch.autograd.Function):
         training, relu, synced = ctx.cfg
         gx, gw, gb = _bn_backward(_f32c(g), x, bias, mean, rstd, weight, n_tot, training, relu, synced)
         return gx, gw, gb, None, None, None, None, None, None, None, None
+
+
+class BnRowsFn(torch.autograd.Function):
+    """``act(BatchNorm(x))[idx]`` -- LightpathGNN normalises the whole node matrix and keeps the LUT nodes' rows
+    (``lightpath_training/models.py:31-32`` then ``:35-40``); one row in ten at cfg3.  Same statistics, running-statistics
+    update and distributed behaviour as ``BnFn`` (they are those of ALL rows); the normalised matrix is never formed: the
+    forward writes the ``n`` consumed rows only, the backward takes its column sums over those rows (the others' gradient
+    is zero) and writes the dense ``grad_x`` -- every row feels the batch statistics -- without a zero-filled ``[N, C]``
+    gradient ever being scattered into or read.  ``grad_x`` is bit for bit ``BnFn`` + ``RowsGatherFn``'s for the same column
+    sums; those differ from the dense path's in the last bit (same terms, other order).  ``idx32``: unique rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, sync, partials, idx32):
+        require_cuda(x, weight, bias, idx32)
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, C = x.shape
+        n = idx32.numel()
+        mean, rstd, n_tot, world = _bn_statistics(x, running_mean, running_var, training, momentum, eps, sync, partials)
+        y = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        if n > 0:
+            _lib.call("qot_bn_apply_rows", P(x), P(idx32), n, P(mean), P(rstd), P(weight), P(bias), P(y), C, int(relu))
+        ctx.save_for_backward(x, bias, mean, rstd, weight, n_tot if n_tot is not None else torch.empty(0), idx32)
+        ctx.cfg = (bool(training), bool(relu), world > 1)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, mean, rstd, weight, n_tot, idx32 = ctx.saved_tensors
+        training, relu, synced = ctx.cfg
+        g = _f32c(g)
+        N, C = x.shape
+        n = idx32.numel()
+        dev = x.device
+        gw = torch.zeros(C, dtype=torch.float32, device=dev)
+        gb = torch.zeros(C, dtype=torch.float32, device=dev)
+        if n > 0:
+            part = torch.empty(_lib.load().qot_bn_partials_floats(n, C), dtype=torch.float32, device=dev)
+            _lib.call("qot_bn_bwd_reduce_rows", P(g), P(idx32), n, P(x), P(mean), P(rstd), P(gw), P(gb), C, int(relu),
+                      P(part), P(weight), P(bias))
+        if not training:              # running statistics: rows without a gradient get none
+            gfull = torch.zeros(N, C, dtype=torch.float32, device=dev)
+            if n > 0:
+                _lib.call("qot_rows_scatter", P(g), P(idx32), P(gfull), n, C)
+            gx = torch.empty_like(x)
+            _lib.call("qot_bn_bwd_apply", P(gfull), None, P(x), P(mean), P(rstd), P(weight), P(gw), P(gb), P(gx), N, C,
+                      int(relu), 0, P(bias))
+            return gx, gw, gb, None, None, None, None, None, None, None, None, None
+        gw_use, gb_use = gw, gb
+        if synced:
+            dist, _ = _dist_world()
+            tot = torch.cat([gw, gb]).double()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            scale = float(N) / n_tot  # the kernel divides by the LOCAL row count: pre-scale the global sums
+            gw_use = (tot[:C] * scale).float().contiguous()
+            gb_use = (tot[C:] * scale).float().contiguous()
+        gx = torch.empty_like(x)
+        _lib.call("qot_bn_bwd_apply_rows", P(g), P(idx32), n, P(x), P(mean), P(rstd), P(weight), P(gw_use), P(gb_use), P(gx),
+                  N, C, int(relu), P(bias))
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 def _bn_backward(g, x, bias, mean, rstd, weight, n_tot, training, relu, synced):

@@ -44,7 +44,7 @@ class LightpathGNN(nn.Module):
         self._qot_cp = None if hidden_channels in GAT_WIDTHS else padded_width(hidden_channels, GAT_WIDTHS)
         self._qot_shadow = None
 
-    def _lut_rows(self, data):
+    def _lut_rows(self, data, check: bool = True):
         """Indices of LUT nodes: ``data.x[:, is_lut_index] == 1.0`` on the RAW input
         (models.py:35).  The ``ValueError`` and the data-dependent output length are part
         of the reference contract, so one host sync per distinct batch is unavoidable; the
@@ -58,7 +58,7 @@ class LightpathGNN(nn.Module):
             idx = (x0[:, self.is_lut_index] == 1.0).nonzero().squeeze(1)
             if c is not None:
                 c["lut"] = (tag, idx)
-        if idx.numel() == 0 and not self.allow_empty_lut:
+        if check and idx.numel() == 0 and not self.allow_empty_lut:
             raise ValueError("No LUT node found in the batch.")
         return idx
 
@@ -95,6 +95,8 @@ class LightpathGNN(nn.Module):
         x, edge_index, batch = data.x, data.edge_index, data.batch
         n = x.shape[0]
         graph = graph_index_for(data, n, gat_self_loops=True)
+        lut_idx = self._lut_rows(data, check=False)     # (the reference's LUT-less error comes after the layers: below)
+        lut_embedding = None
         pending = None             # (norm, raw conv output, BatchNorm partials) whose BatchNorm + ReLU the next projection applies
         for layer in range(1, self.num_layers + 1):
             conv, norm = getattr(self, f"conv{layer}"), getattr(self, f"norm{layer}")
@@ -121,12 +123,17 @@ class LightpathGNN(nn.Module):
             if (layer < self.num_layers and QF.gemm_ok(width, width) and raw.shape[0] > 0
                     and getattr(self, "_qot_fuse_bn_projection", os.environ.get("QOT_FUSE_BN_PROJECTION", "1") != "0")):
                 pending = (norm, raw, partials)
+            elif (layer == self.num_layers and lut_idx.numel() > 0 and raw.shape[0] > 0
+                  and os.environ.get("QOT_NO_BN_ROWS", "0") != "1"):
+                # the last BatchNorm + ReLU feeds nothing but the LUT rows: only those rows of it are formed (QF.BnRowsFn)
+                lut_embedding = norm.rows(raw, to_i32(lut_idx), relu=True, partials=partials)
             else:
                 x = norm(raw, relu=True, partials=partials)        # BatchNorm + F.relu fused, materialised
         idx = self._lut_rows(data)
         if idx.numel() == 0:          # only with allow_empty_lut: zero rows that still hang on the graph
             return x[:0, :self.mlp[3].out_features], batch[:0]
-        lut_embedding = QF.RowsGatherFn.apply(x, to_i32(idx))
+        if lut_embedding is None:
+            lut_embedding = QF.RowsGatherFn.apply(x, to_i32(idx))
         lut_batch = batch.index_select(0, idx)
         l0, act, drop, l3 = self.mlp[0], self.mlp[1], self.mlp[2], self.mlp[3]
         h = QF.SmallLinearFn.apply(lut_embedding, l0.weight, l0.bias)       # head MLP (models.py:17-22,43)

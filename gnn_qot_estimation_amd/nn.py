@@ -228,6 +228,17 @@ class BatchNorm(nn.Module):
         return QF.BnFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training,
                              m.momentum, m.eps, relu, self.sync_stats, partials)
 
+    def rows(self, x, idx32, relu: bool = False, partials=None):
+        """``self(x, relu)[idx32]`` for unique rows ``idx32`` with only those rows of the normalised matrix ever formed
+        (``QF.BnRowsFn``); statistics and running statistics are those of all rows, as in ``forward``."""
+        m = self.module
+        if self.training:
+            m.num_batches_tracked.add_(1)
+        if partials is not None and not (self.training and QF._dist_world()[1] == 1):
+            partials = None
+        return QF.BnRowsFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum, m.eps, relu,
+                                 self.sync_stats, partials, idx32)
+
     def project_relu(self, x, lin_weight, partials=None, att=None):
         """``relu(self(x)) @ lin_weight^T`` without materialising the normalised activations (``QF.BnLinearFn``): this
         layer's BatchNorm + ReLU ride in the operand load of the next layer's projection.  ``att = (att_src, att_dst)`` of

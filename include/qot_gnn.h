@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 8
+#define QOT_ABI_VERSION 9
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -377,6 +377,20 @@ int qot_bn_bwd_apply(const float* grad_y, const float* y, const float* x, const 
                      const float* rstd, const float* w, const float* gw, const float* gb,
                      float* grad_x, int64_t N, int C, int relu, int batch_stats, const float* b,
                      qot_stream_t stream);
+/* BatchNorm(+ReLU) of which only some rows are consumed: y_rows = act(BatchNorm(x))[idx] -- LightpathGNN normalises the
+ * whole node matrix and then keeps the LUT nodes' rows (lightpath_training/models.py:31-32, 35-40).  Statistics over all
+ * N rows as before (qot_bn_stats / qot_bn_stats_from_partials); idx: n unique row numbers.
+ * qot_bn_apply_rows: the n output rows only.  qot_bn_bwd_reduce_rows: the column sums over the n rows that carry a
+ * gradient (partials: qot_bn_partials_floats(n, C) floats).  qot_bn_bwd_apply_rows: grad_x [N, C] (batch-statistics
+ * form), bit for bit what qot_bn_bwd_apply gives for the zero-filled [N, C] gradient with grad_rows scattered into it. */
+int qot_bn_apply_rows(const float* x, const int32_t* idx, int64_t n, const float* mean, const float* rstd, const float* w,
+                      const float* b, float* y_rows, int C, int relu, qot_stream_t stream);
+int qot_bn_bwd_reduce_rows(const float* grad_rows, const int32_t* idx, int64_t n, const float* x, const float* mean,
+                           const float* rstd, float* gw, float* gb, int C, int relu, float* partials, const float* w,
+                           const float* b, qot_stream_t stream);
+int qot_bn_bwd_apply_rows(const float* grad_rows, const int32_t* idx, int64_t n, const float* x, const float* mean,
+                          const float* rstd, const float* w, const float* gw, const float* gb, float* grad_x, int64_t N,
+                          int C, int relu, const float* b, qot_stream_t stream);
 
 /* ---- train-step envelope helpers (topological_training/train.py:109-116) ----------------
  * qot_sgd_momentum: torch.optim.SGD(lr, momentum) update over one flat buffer; first_step != 0

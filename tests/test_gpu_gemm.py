@@ -160,3 +160,69 @@ def test_skinny_projection_logits_match_fp64(cuda_device, N, F, C):
     assert _rel(out, ref) <= 1e-5
     assert _rel(a_s, (ref.view(N, heads, 128) * att_s.double().view(heads, 128)).sum(-1)) <= 1e-5
     assert _rel(a_d, (ref.view(N, heads, 128) * att_d.double().view(heads, 128)).sum(-1)) <= 1e-5
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("N,C,n", [(5000, 512, 613), (300, 128, 300), (77, 32, 1)])
+def test_batchnorm_rows_form_equals_dense_batchnorm_then_gather(cuda_device, training, N, C, n):
+    """QF.BnRowsFn (only the consumed rows of relu(BatchNorm(x)) are formed; lightpath_training/models.py:31-32, 35-40)
+    against BnFn + RowsGatherFn: outputs and running statistics bit for bit, parameter gradients to fp32 rounding (same
+    terms, other order), grad_x bit for bit once both paths are given the same column sums."""
+    from gnn_qot_estimation_amd import functional as QF, _lib
+    torch.manual_seed(3)
+    dev = cuda_device
+    x0 = torch.randn(N, C, device=dev) * 2 + 0.5
+    idx = torch.randperm(N, device=dev)[:n].sort().values.to(torch.int32)
+    g = torch.randn(n, C, device=dev)
+    w0, b0 = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    res = []
+    for rows in (False, True):
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if rows:
+            y = QF.BnRowsFn.apply(x, w, b, rm, rv, training, 0.1, 1e-5, True, False, None, idx)
+        else:
+            y = QF.RowsGatherFn.apply(QF.BnFn.apply(x, w, b, rm, rv, training, 0.1, 1e-5, True, False, None), idx)
+        y.backward(g)
+        res.append((y.detach(), rm, rv, x.grad, w.grad, b.grad))
+    a, r = res
+    assert torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]) and torch.equal(a[2], r[2])
+    for k in (4, 5):
+        assert float((a[k] - r[k]).abs().max()) <= 2e-5 * float(a[k].abs().max().clamp_min(1.0))
+    assert float((a[3] - r[3]).abs().max()) <= 1e-5 * float(a[3].abs().max().clamp_min(1e-3))
+    if training:
+        # same column sums in: the two-pass rows kernel reproduces the dense kernel's bits
+        P = lambda t: t
+        x = x0
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        rstd = (var + 1e-5).rsqrt()
+        w, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        gw, gb = torch.randn(C, device=dev), torch.randn(C, device=dev)
+        gfull = torch.zeros(N, C, device=dev)
+        gfull[idx.long()] = g
+        dense, rowsf = torch.empty(N, C, device=dev), torch.full((N, C), float("nan"), device=dev)
+        _lib.call("qot_bn_bwd_apply", gfull, None, x, mean, rstd, w, gw, gb, dense, N, C, 1, 1, b)
+        _lib.call("qot_bn_bwd_apply_rows", g, idx, n, x, mean, rstd, w, gw, gb, rowsf, N, C, 1, b)
+        assert torch.equal(dense, rowsf)
+
+
+@pytest.mark.parametrize("m,k,n", [(65536, 128, 1), (5000, 64, 3), (4096, 512, 8)])
+def test_small_linear_thin_output_weight_gradient_matches_fp64(cuda_device, m, k, n):
+    """SmallLinearFn for a handful of outputs over many rows (LightpathGNN's last Linear, models.py:17-22): the weight
+    gradient goes through the skinny row-parallel kernel with the operands' roles swapped."""
+    from gnn_qot_estimation_amd import functional as QF
+    torch.manual_seed(4)
+    dev = cuda_device
+    x = torch.randn(m, k, device=dev, requires_grad=True)
+    w = (torch.randn(n, k, device=dev) / k ** 0.5).requires_grad_(True)
+    b = torch.randn(n, device=dev, requires_grad=True)
+    g = torch.randn(m, n, device=dev)
+    y = QF.SmallLinearFn.apply(x, w, b)
+    y.backward(g)
+    xd, wd, gd = x.detach().double(), w.detach().double(), g.double()
+    assert _rel(y.detach(), xd @ wd.t() + b.detach().double()) <= 1e-5
+    assert _rel(w.grad, gd.t() @ xd) <= 2e-5
+    assert _rel(x.grad, gd @ wd) <= 1e-5
+    assert _rel(b.grad, gd.sum(0)) <= 2e-5
