@@ -29,7 +29,10 @@ __device__ __forceinline__ f32x16 mfma_group(const float4* __restrict__ At4, int
 // Accumulators in AGPRs.  At <= 256 registers per lane and no other AGPR use the compiler selects the MFMAs' VGPR form
 // (dst / srcC in the architectural file); one inline-asm operand with an "a" constraint makes it select the AGPR form for
 // the whole kernel: the accumulator traffic of the matrix pipe then stays off the ports the LDS / global load returns and
-// the VALU use (measured in gemm.hip, tools/bench_gemm_k.py).  Call once at the top of a kernel.
+// the VALU use (gemm.hip, tools/bench_gemm_k.py: +1..3 %).  Call once at the top of a kernel.  Only for kernels that fit
+// 128 architectural registers besides the accumulators: under __launch_bounds__(256, 2) the AGPR form splits the 256
+// registers 128 / 128, and the fused NNConv kernels (180-254 VGPRs) then spill into AGPR copies -- measured with the
+// hint in nnconv_gen.hip: cfg4 28.6 -> 32.6 ms, cfg5 13.9 -> 15.7 ms; nnconv_mfma64 98.5 -> 101 us.  They keep the VGPR form.
 __device__ __forceinline__ void mfma_acc_in_agprs() {
 #ifndef QOT_NO_AGPR_HINT
     float az = 0.f;
