@@ -33,6 +33,9 @@ SIGNATURES = {
     "qot_error_string": (C.c_char_p, [_int]),
     "qot_csr_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "qot_csr_build": (_int, [_p, _i64, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "qot_csr_gat_by_graph_supported": (_int, [_i64, _i64]),
+    "qot_csr_build_gat_by_graph": (_int, [_p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                          _p]),
     "qot_csr_build_by_graph": (_int, [_p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                       _p, _p, _p, _p, _p, _p, _p]),
     "qot_i32_gather": (_int, [_p, _p, _p, _i64, _p]),

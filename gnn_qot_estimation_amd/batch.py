@@ -30,6 +30,9 @@ class Data:
         self.ptr = None
         self.edge_ptr = None        # Batch: per-graph edge offsets [B+1]; graph_sizes: (max nodes, max edges)
         self.graph_sizes = None
+        # Batch: False when the collate step has seen that no edge joins a node with itself (host-side check); with the
+        # edge slices this lets GATConv's self-looped index be built one graph per wave (qot_csr_build_gat_by_graph)
+        self.has_self_loops = None
         self._num_nodes = num_nodes
 
     @property
@@ -101,6 +104,8 @@ class Batch(Data):
         ecounts = [g.num_edges for g in graphs]
         out.edge_ptr = torch.tensor([0] + ecounts, dtype=torch.long).cumsum(0)
         out.graph_sizes = (max(sizes, default=0), max(ecounts, default=0))
+        ei = out.edge_index
+        out.has_self_loops = bool((ei[0] == ei[1]).any()) if not ei.is_cuda else None
         return out
 
 
@@ -175,6 +180,7 @@ def shard_graphs(batch: Batch, rank: int, world: int, balance: str = "graphs") -
     if ep is not None and bool(keep[int(ep[lo]):int(ep[hi])].all()) and int(keep.sum()) == int(ep[hi] - ep[lo]):
         out.edge_ptr = ep[lo:hi + 1] - ep[lo]
         out.graph_sizes = getattr(batch, "graph_sizes", None)
+        out.has_self_loops = False if getattr(batch, "has_self_loops", None) is False else None
     if batch.y is not None:
         per = batch.y.shape[0] // max(b, 1)
         out.y = batch.y[lo * per:hi * per]

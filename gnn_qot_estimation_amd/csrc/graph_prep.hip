@@ -6,6 +6,7 @@
 // later segmented reduction has a fixed summation order (bitwise reproducible).
 #include "common.hpp"
 #include "graph_prep_dev.hpp"
+#include "mfma_tile.hpp"
 
 namespace qot {
 
@@ -289,6 +290,156 @@ extern "C" int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int6
     for (int k = 0; k < 18; ++k) r.p[k] = ptrs[k];
     r.i[0] = E; r.i[1] = N; r.i[2] = B; r.i[3] = max_nodes; r.i[4] = max_edges;
     return qot_run_roles(&r, 1, stream_);
+}
+
+// ---- GAT mode, block-diagonal batches of SMALL graphs: one wave per graph, one launch ---------------------------
+// LightpathGNN's batches are tens of thousands of chain graphs of 2..20 nodes (lightpath_training/dataset.py); PyG
+// rebuilds their self-looped edge list in every GATConv call (lightpath_training/models.py:30).  With the graphs' node
+// and edge slices known and NO self loop in the input (the collate step's host-side check; one is flagged, bit 4 of
+// status, never mis-built) graph b owns slots [e0 + n0, e0 + n0 + m + n) of the self-looped index whatever the other
+// graphs hold, so a wave builds it alone from its own LDS: in-row order = edge id, the inserted self loop last (key
+// E + i, eid -1) -- bit for bit qot_csr_build(gat_self_loops = 1).  n <= 64 (one lane per node), m <= 256.
+constexpr int kGatSmallMaxN = 64, kGatSmallMaxM = 256;
+constexpr int kGatSmallLds = 3 * kGatSmallMaxM + 2 * (kGatSmallMaxN + 1);
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int* total) {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    *total = __shfl(inc, 63);
+    return inc - v;
+}
+
+__global__ __launch_bounds__(256) void csr_gat_small_kernel(
+    const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t B, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+    int32_t* __restrict__ eid, int32_t* __restrict__ row, int32_t* __restrict__ rowptr_t, int32_t* __restrict__ col_t,
+    int32_t* __restrict__ pos_t, int32_t* __restrict__ eid_t, float* __restrict__ invdeg, int32_t* __restrict__ status,
+    int32_t* __restrict__ ptr32) {
+    __shared__ int lds[4][kGatSmallLds];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* lsrc = lds[wave];
+    int* ldst = lsrc + kGatSmallMaxM;
+    int* rp = ldst + kGatSmallMaxM;
+    int* rpt = rp + kGatSmallMaxN + 1;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    // A graph costs two dependent global round trips (its slices, then its edges) and a wave walks ~8 graphs: the NEXT
+    // graph's slices and its first 64 edges are requested before the current graph is worked on (raw values only: no
+    // arithmetic on them before the wait -- the compiler would put it right behind the load).
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    int64_t q_n0 = 0, q_n1 = 0, q_e0 = 0, q_e1 = 0, q_j = 0, q_i = 0;
+    if (b < B) {
+        q_n0 = node_ptr[b]; q_n1 = node_ptr[b + 1]; q_e0 = edge_ptr[b]; q_e1 = edge_ptr[b + 1];
+        if (q_e0 >= 0 && q_e0 + lane < q_e1 && q_e1 <= E) { q_j = ei[q_e0 + lane]; q_i = ei[E + q_e0 + lane]; }
+    }
+    for (; b < B; b += nwaves) {
+        const int64_t n0 = q_n0, e0 = q_e0;
+        const int64_t nn = q_n1 - n0, mm = q_e1 - e0;
+        const int64_t first_j = q_j, first_i = q_i;
+        {
+            const int64_t bn = b + nwaves;
+            if (bn < B) {
+                q_n0 = node_ptr[bn]; q_n1 = node_ptr[bn + 1]; q_e0 = edge_ptr[bn]; q_e1 = edge_ptr[bn + 1];
+                if (q_e0 >= 0 && q_e0 + lane < q_e1 && q_e1 <= E) { q_j = ei[q_e0 + lane]; q_i = ei[E + q_e0 + lane]; }
+            }
+        }
+        if (lane == 0) {
+            if (ptr32) {
+                ptr32[b] = (int32_t)n0;
+                if (b == B - 1) ptr32[B] = (int32_t)node_ptr[B];
+            }
+            if (b == B - 1) { rowptr[N] = (int32_t)(E + N); rowptr_t[N] = (int32_t)(E + N); }
+        }
+        // host-side size bound violated, or slices that do not lie inside the arrays: flag, write nothing
+        if (nn > kGatSmallMaxN || mm > kGatSmallMaxM || nn < 0 || mm < 0 || n0 < 0 || e0 < 0 || n0 + nn > N || e0 + mm > E) {
+            if (lane == 0 && status) atomicOr(status, 2);
+            continue;
+        }
+        const int n = (int)nn, m = (int)mm;
+        const int64_t s0 = e0 + n0;
+        bool bad = false, loop = false;
+        for (int e = lane; e < m; e += 64) {
+            int j = (int)((e < 64 ? first_j : ei[e0 + e]) - n0), i = (int)((e < 64 ? first_i : ei[E + e0 + e]) - n0);
+            if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
+            if (i == j) loop = true;
+            lsrc[e] = j;
+            ldst[e] = i;
+        }
+        if (status) {
+            if (bad) atomicOr(status, 1);
+            if (loop) atomicOr(status, 4);
+        }
+        wave_lds_fence();
+        // lane i = node i: degrees (the edge list is read as broadcasts), offsets, its self loop
+        int din = 0, dout = 0;
+        for (int e = 0; e < m; ++e) {
+            din += (ldst[e] == lane) ? 1 : 0;
+            dout += (lsrc[e] == lane) ? 1 : 0;
+        }
+        int tot;
+        const int rpi = wave_exclusive_scan(lane < n ? din + 1 : 0, lane, &tot);
+        const int rpti = wave_exclusive_scan(lane < n ? dout + 1 : 0, lane, &tot);
+        if (lane < n) {
+            rp[lane] = rpi;
+            rpt[lane] = rpti;
+            rowptr[n0 + lane] = (int32_t)(s0 + rpi);
+            rowptr_t[n0 + lane] = (int32_t)(s0 + rpti);
+            invdeg[n0 + lane] = 1.0f / (float)(din + 1);
+            const int64_t p = s0 + rpi + din, pt = s0 + rpti + dout;
+            col[p] = (int32_t)(n0 + lane);
+            eid[p] = -1;
+            row[p] = (int32_t)(n0 + lane);
+            col_t[pt] = (int32_t)(n0 + lane);
+            eid_t[pt] = -1;
+            pos_t[pt] = (int32_t)p;
+        }
+        wave_lds_fence();
+        // lane per edge: rank among the earlier edges of the same row = its place in edge-id order
+        for (int e = lane; e < m; e += 64) {
+            const int i = ldst[e], j = lsrc[e];
+            int rin = 0, rout = 0;
+            for (int f = 0; f < e; ++f) {
+                rin += (ldst[f] == i) ? 1 : 0;
+                rout += (lsrc[f] == j) ? 1 : 0;
+            }
+            const int64_t p = s0 + rp[i] + rin, pt = s0 + rpt[j] + rout;
+            col[p] = (int32_t)(n0 + j);
+            eid[p] = (int32_t)(e0 + e);
+            row[p] = (int32_t)(n0 + i);
+            col_t[pt] = (int32_t)(n0 + i);
+            eid_t[pt] = (int32_t)(e0 + e);
+            pos_t[pt] = (int32_t)p;
+        }
+        wave_lds_fence();                                  // the next graph's stores come after these reads
+    }
+}
+
+extern "C" int qot_csr_gat_by_graph_supported(int64_t max_nodes, int64_t max_edges) {
+    return max_nodes >= 0 && max_edges >= 0 && max_nodes <= kGatSmallMaxN && max_edges <= kGatSmallMaxM;
+}
+
+extern "C" int qot_csr_build_gat_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
+                                          const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges,
+                                          int32_t* rowptr, int32_t* col, int32_t* eid, int32_t* row, int32_t* rowptr_t,
+                                          int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg, int32_t* status,
+                                          int32_t* ptr32, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (E < 0 || N < 0 || B <= 0 || !edge_index || !node_ptr || !edge_ptr || !rowptr || !col || !eid || !row || !rowptr_t ||
+        !col_t || !pos_t || !eid_t || !invdeg)
+        return QOT_ERR_BADARG;
+    if (!qot_csr_gat_by_graph_supported(max_nodes, max_edges) || E + N > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+    int64_t wgs = (B + 3) / 4;
+    const int64_t cap = 8 * (int64_t)num_cus();            // 32 waves per CU (3.6 KB of LDS each)
+    if (wgs > cap) wgs = cap;
+    csr_gat_small_kernel<<<(int)wgs, 256, 0, stream>>>(edge_index, E, N, node_ptr, edge_ptr, B, rowptr, col, eid, row,
+                                                      rowptr_t, col_t, pos_t, eid_t, invdeg, status, ptr32);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
 }
 
 extern "C" int qot_i32_gather(const int32_t* map, const int32_t* idx, int32_t* out, int64_t n, qot_stream_t stream) {

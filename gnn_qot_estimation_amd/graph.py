@@ -10,6 +10,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -36,6 +38,7 @@ class GraphIndex:
     colf_t: Optional[torch.Tensor] = None   # [E] int32 node_ids[col_t]
     ptr32: Optional[torch.Tensor] = None    # [B+1] int32 graph boundaries
     sizes: Optional[tuple] = None           # (max nodes, max edges) of one graph: the per-graph build has checked every slice
+    status_pending: bool = False            # built with check=False: the caller still owes a check_index_status()
 
 
 def require_cuda(*tensors):
@@ -82,12 +85,14 @@ def check_index_status(dev) -> None:
             what.append("an edge leaves its graph's node range")
         if code & 2:
             what.append("a graph slice lies outside the node / edge arrays or exceeds (max_nodes, max_edges)")
+        if code & 4:
+            what.append("edge_index holds a self loop although the batch says has_self_loops = False")
         raise _lib.QotError("qot_csr_build_by_graph: inconsistent batch slices (" + "; ".join(what) + "): ptr / edge_ptr "
                             "do not describe edge_index -- pass slices=None for the general build")
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: bool = False,
-                      slices=None, node_ids: Optional[torch.Tensor] = None, group=None) -> GraphIndex:
+                      slices=None, node_ids: Optional[torch.Tensor] = None, group=None, check: bool = True) -> GraphIndex:
     """``slices = (node_ptr, edge_ptr, max_nodes, max_edges)`` (int64 device tensors ``[B+1]`` and host
     ints) marks a block-diagonal batch whose graphs keep nodes and edges contiguous: the index is then
     built by one workgroup per graph in a single launch (``qot_csr_build_by_graph``).  ``group`` (a
@@ -144,6 +149,23 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, gat_self_loops: 
             if CHECK_INDEX_STATUS:
                 check_index_status(dev)
             return g
+    if slices is not None and gat_self_loops:
+        # GATConv's self-looped index of a batch of small graphs without self loops (the caller vouches for that:
+        # graph_index_for passes slices in GAT mode only for has_self_loops == False): one launch, one wave per graph
+        node_ptr, edge_ptr, max_n, max_m = slices
+        B = node_ptr.numel() - 1
+        if (B >= 1 and edge_ptr.numel() == B + 1 and node_ptr.is_cuda and edge_ptr.is_cuda and node_ptr.dtype == torch.long
+                and edge_ptr.dtype == torch.long and lib.qot_csr_gat_by_graph_supported(int(max_n), int(max_m))):
+            g.ptr32 = torch.empty(B + 1, **i32)
+            np_c, ep_c = node_ptr.contiguous(), edge_ptr.contiguous()     # named: see above
+            status = _index_status(dev)
+            _lib.call("qot_csr_build_gat_by_graph", ei, E, N, np_c, ep_c, B, int(max_n), int(max_m), g.rowptr, g.col, g.eid,
+                      g.row, g.rowptr_t, g.col_t, g.pos_t, g.eid_t, g.invdeg, status, g.ptr32)
+            if CHECK_INDEX_STATUS and check:     # check=False: the caller reads the flag itself, behind its next host sync
+                check_index_status(dev)
+            else:
+                g.status_pending = CHECK_INDEX_STATUS
+            return g
     ws_bytes = lib.qot_csr_workspace_bytes(E, N, int(gat_self_loops))
     if ws_bytes == 0:
         raise _lib.QotError("qot_csr_workspace_bytes failed")
@@ -165,8 +187,10 @@ def _cache(data) -> Optional[dict]:
     return c
 
 
-def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False, group=None) -> GraphIndex:
-    """Cached ``GraphIndex`` of ``data.edge_index`` (rebuilt if the tensor changed).  ``group``: see ``build_graph_index``."""
+def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False, group=None, check: bool = True) -> GraphIndex:
+    """Cached ``GraphIndex`` of ``data.edge_index`` (rebuilt if the tensor changed).  ``group``: see ``build_graph_index``.
+    ``check=False`` (GAT mode): the one-launch build's status word is not read back here -- the caller calls
+    ``check_index_status`` itself, behind a host synchronisation it has anyway."""
     ei = data.edge_index
     key = ("graph", bool(gat_self_loops))
     tag = (ei.data_ptr(), ei._version, tuple(ei.shape), int(num_nodes))
@@ -186,11 +210,12 @@ def graph_index_for(data, num_nodes: int, gat_self_loops: bool = False, group=No
             sizes = (int((pc[1:] - pc[:-1]).max()), int((es[1:] - es[:-1]).max()))
             if c is not None:
                 c["ptr_host"] = pc
-    if (not gat_self_loops and ptr is not None and eptr is not None and sizes is not None
-            and ptr.numel() == eptr.numel() and ptr.is_cuda and eptr.is_cuda):
+    if (ptr is not None and eptr is not None and sizes is not None and ptr.numel() == eptr.numel() and ptr.is_cuda
+            and eptr.is_cuda and (not gat_self_loops or (getattr(data, "has_self_loops", None) is False
+                                                         and os.environ.get("QOT_NO_GAT_BY_GRAPH", "0") != "1"))):
         slices = (ptr, eptr, sizes[0], sizes[1])
     ids = getattr(data, "node_ids", None) if (slices is not None and getattr(data, "uniform_node_ids", None)) else None
-    g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids, group=group)
+    g = build_graph_index(ei, num_nodes, gat_self_loops, slices, ids, group=group, check=check)
     if c is not None:
         def remember():
             c[key] = (tag, g)

@@ -14,7 +14,7 @@ import os
 from torch import nn
 
 from . import functional as QF
-from .graph import _cache, graph_index_for, to_i32
+from .graph import _cache, check_index_status, graph_index_for, to_i32
 from .nn import BatchNorm, GATConv
 
 
@@ -94,8 +94,12 @@ class LightpathGNN(nn.Module):
             return self._forward_padded(data)
         x, edge_index, batch = data.x, data.edge_index, data.batch
         n = x.shape[0]
-        graph = graph_index_for(data, n, gat_self_loops=True)
+        graph = graph_index_for(data, n, gat_self_loops=True, check=False)
         lut_idx = self._lut_rows(data, check=False)     # (the reference's LUT-less error comes after the layers: below)
+        if graph.status_pending:
+            # the one-launch index build's status word, read behind the host synchronisation the LUT rows cost anyway
+            graph.status_pending = False
+            check_index_status(x.device)
         lut_embedding = None
         pending = None             # (norm, raw conv output, BatchNorm partials) whose BatchNorm + ReLU the next projection applies
         for layer in range(1, self.num_layers + 1):

@@ -100,6 +100,7 @@ def collate_into(graphs: Sequence[Data], st: Optional[_Staging]) -> Batch:
     out.ptr, out.batch, out.edge_index = ptr, batch, ei
     out.edge_ptr = eptr
     out.graph_sizes = (max(sizes, default=0), max(edges, default=0))
+    out.has_self_loops = bool((ei[0] == ei[1]).any())
     for name in ("x", "edge_attr", "node_ids", "y"):
         setattr(out, name, cat_fields[name][0] if name in cat_fields else None)
     out.uniform_node_ids = None
@@ -134,6 +135,7 @@ class PackedGraphs:
         self.y_rows = 0 if y is None else y.shape[0] // max(len(self), 1)
         ncnt, ecnt = node_ptr[1:] - node_ptr[:-1], edge_ptr[1:] - edge_ptr[:-1]
         self.graph_sizes = (int(ncnt.max()) if ncnt.numel() else 0, int(ecnt.max()) if ecnt.numel() else 0)
+        self.has_self_loops = bool((edge_index[0] == edge_index[1]).any()) if not edge_index.is_cuda else None
         self.pinned = False
         self.device = None          # set by to_device(): the shard lives in HBM
 
@@ -202,6 +204,7 @@ class PackedGraphs:
         out.ptr = self.node_ptr_dev[lo:hi + 1] - n0
         out.edge_ptr = self.edge_ptr_dev[lo:hi + 1] - e0
         out.graph_sizes = self.graph_sizes
+        out.has_self_loops = False if self.has_self_loops is False else None
         out.batch = self.graph_of_node[n0:n1] - lo
         if cache:
             self._batch_cache[(lo, hi)] = out
@@ -253,6 +256,7 @@ class PackedGraphs:
                 eptr.sub_(e0)
             out.edge_ptr = eptr
             out.graph_sizes = self.graph_sizes
+            out.has_self_loops = False if self.has_self_loops is False else None
             counts = ptr[1:] - ptr[:-1]
             bt = st.dev_view("batch", (n1 - n0,), torch.long)
             bt.copy_(torch.repeat_interleave(torch.arange(hi - lo, device=dev), counts, output_size=n1 - n0))
@@ -326,6 +330,7 @@ class GraphLoader:
         dev = Batch()
         dev.num_graphs, dev._num_nodes, dev.uniform_node_ids = host.num_graphs, host._num_nodes, host.uniform_node_ids
         dev.graph_sizes = host.graph_sizes
+        dev.has_self_loops = host.has_self_loops
         # the device buffers of this slot were last read `depth` batches ago: the copy stream must
         # not overwrite them before that step's kernels are done
         self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))

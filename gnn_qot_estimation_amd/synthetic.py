@@ -138,4 +138,5 @@ def tile_batch(base: Batch, times: int) -> Batch:
         e = base.num_edges
         out.edge_ptr = torch.cat([base.edge_ptr[:-1] + k * e for k in range(times)] + [torch.tensor([e * times])])
         out.graph_sizes = base.graph_sizes
+        out.has_self_loops = getattr(base, "has_self_loops", None)
     return out

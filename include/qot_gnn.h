@@ -93,6 +93,18 @@ int qot_csr_build_by_graph(const int64_t* edge_index, int64_t E, int64_t N, cons
                            int32_t* col_t, int32_t* pos_t, int32_t* eid_t, float* invdeg, int32_t* status,
                            const int64_t* node_ids, int32_t* ids32, int32_t* colf, int32_t* colf_t, int32_t* ptr32,
                            qot_stream_t stream);
+/* GATConv's self-looped index (qot_csr_build with gat_self_loops = 1: PyG GATConv rebuilds it in every call,
+ * lightpath_training/models.py:30) of a block-diagonal batch of SMALL graphs -- LightpathGNN's chain graphs of 2..20
+ * nodes -- in one launch, one wave per graph.  Requires max_nodes <= 64, max_edges <= 256
+ * (qot_csr_gat_by_graph_supported; QOT_ERR_UNSUPPORTED otherwise) and an input WITHOUT self loops: then graph b owns the
+ * slots [edge_ptr[b] + node_ptr[b], ... + m + n) whatever the other graphs hold.  Output bit for bit qot_csr_build's.
+ * status (optional, device int32): bits 0 / 1 as qot_csr_build_by_graph, bit 2 = a self loop was met (the index is
+ * then wrong: rebuild with qot_csr_build).  ptr32 (optional): node_ptr narrowed to int32. */
+int qot_csr_gat_by_graph_supported(int64_t max_nodes, int64_t max_edges);
+int qot_csr_build_gat_by_graph(const int64_t* edge_index, int64_t E, int64_t N, const int64_t* node_ptr,
+                               const int64_t* edge_ptr, int64_t B, int64_t max_nodes, int64_t max_edges, int32_t* rowptr,
+                               int32_t* col, int32_t* eid, int32_t* row, int32_t* rowptr_t, int32_t* col_t, int32_t* pos_t,
+                               int32_t* eid_t, float* invdeg, int32_t* status, int32_t* ptr32, qot_stream_t stream);
 /* out[i] = map[idx[i]] (int32): table row of every CSR / CSC slot's source / destination
  * (node_ids[col], node_ids[col_t]) for TransformerConv's table mode.  idx values must be < len(map). */
 int qot_i32_gather(const int32_t* map, const int32_t* idx, int32_t* out, int64_t n, qot_stream_t stream);

@@ -1,0 +1,98 @@
+"""GATConv's self-looped graph index of a batch of small graphs, one wave per graph in one launch
+(qot_csr_build_gat_by_graph; PyG rebuilds that edge list in every GATConv call, lightpath_training/models.py:30),
+against the general multi-launch build: bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("rowptr", "col", "eid", "row", "rowptr_t", "col_t", "pos_t", "eid_t", "invdeg")
+
+
+def _random_small_batch(sizes, ecnt, seed=0, chain=False):
+    g = torch.Generator().manual_seed(seed)
+    ptr = torch.tensor([0] + sizes).cumsum(0)
+    eptr = torch.tensor([0] + ecnt).cumsum(0)
+    parts = []
+    for n, m, off in zip(sizes, ecnt, ptr[:-1].tolist()):
+        if m == 0:
+            continue
+        src = torch.randint(0, n, (m,), generator=g)
+        dst = (src + 1 + torch.randint(0, n - 1, (m,), generator=g)) % n      # never a self loop; duplicates allowed
+        parts.append(torch.stack([src, dst]) + off)
+    ei = torch.cat(parts, 1) if parts else torch.zeros(2, 0, dtype=torch.long)
+    return ei, ptr, eptr
+
+
+def _assert_same(a, b, cap):
+    for name in FIELDS:
+        ta, tb = getattr(a, name), getattr(b, name)
+        m = cap if name not in ("rowptr", "rowptr_t", "invdeg") else ta.numel()
+        assert torch.equal(ta[:m], tb[:m]), name
+
+
+def test_gat_index_by_graph_equals_general_build(cuda_device):
+    from gnn_qot_estimation_amd.graph import build_graph_index
+    dev = cuda_device
+    sizes = [7, 1, 64, 12, 2, 20, 33, 1, 5] * 37               # 333 graphs: single nodes, the 64-node limit, ragged
+    ecnt = [20, 0, 256, 30, 2, 38, 64, 0, 1] * 37
+    ei, ptr, eptr = _random_small_batch(sizes, ecnt)
+    ei = ei.to(dev)
+    N, E = int(ptr[-1]), ei.shape[1]
+    a = build_graph_index(ei, N, gat_self_loops=True)
+    b = build_graph_index(ei, N, gat_self_loops=True, slices=(ptr.to(dev), eptr.to(dev), max(sizes), max(ecnt)))
+    assert b.ptr32 is not None and torch.equal(b.ptr32.long().cpu(), ptr)      # the one-launch build ran
+    _assert_same(a, b, E + N)
+
+
+def test_gat_index_by_graph_flags_self_loops_and_refuses_large_graphs(cuda_device):
+    from gnn_qot_estimation_amd import _lib
+    from gnn_qot_estimation_amd.graph import build_graph_index, check_index_status, _index_status
+    dev = cuda_device
+    sizes, ecnt = [5, 9, 3], [6, 10, 2]
+    ei, ptr, eptr = _random_small_batch(sizes, ecnt, seed=1)
+    ei[1, 7] = ei[0, 7]                                          # a self loop in graph 1
+    ei = ei.to(dev)
+    N = int(ptr[-1])
+    _index_status(dev).zero_()
+    with pytest.raises(_lib.QotError, match="self loop"):
+        build_graph_index(ei, N, gat_self_loops=True, slices=(ptr.to(dev), eptr.to(dev), max(sizes), max(ecnt)))
+    check_index_status(dev)                                     # the flag was consumed by the raise
+    # graphs beyond one wave's reach: the general build, silently
+    g = build_graph_index(ei, N, gat_self_loops=True, slices=(ptr.to(dev), eptr.to(dev), 65, max(ecnt)))
+    assert g.ptr32 is None
+    assert _lib.load().qot_csr_gat_by_graph_supported(64, 256) == 1 and _lib.load().qot_csr_gat_by_graph_supported(64, 257) == 0
+
+
+def test_lightpath_batches_take_the_one_launch_index_and_match_the_general_path(cuda_device, monkeypatch):
+    """A collated lightpath batch carries has_self_loops = False (host-side check at collate time): LightpathGNN then
+    builds its index in one launch; outputs and gradients equal the general build's bit for bit."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    from gnn_qot_estimation_amd.graph import graph_index_for
+    dev = cuda_device
+    batch = S.lightpath_batch(200).to(dev)
+    assert batch.has_self_loops is False
+    torch.manual_seed(0)
+    model = q.LightpathGNN(5, 32, 3, 1, dropout_p=0.0).to(dev).train()
+    res = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("QOT_NO_GAT_BY_GRAPH", off)
+        batch._qot_cache = {}
+        g = graph_index_for(batch, batch.num_nodes, gat_self_loops=True)
+        assert (g.ptr32 is not None) == (off == "0")
+        model.zero_grad(set_to_none=True)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        out, lb = model(batch)
+        out.square().sum().backward()
+        res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert torch.equal(ga, gb)
+    # a batch whose collate step saw a self loop keeps the general build
+    batch.has_self_loops = True
+    batch._qot_cache = {}
+    monkeypatch.setenv("QOT_NO_GAT_BY_GRAPH", "0")
+    assert graph_index_for(batch, batch.num_nodes, gat_self_loops=True).ptr32 is None
