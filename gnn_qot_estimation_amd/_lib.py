@@ -43,6 +43,8 @@ SIGNATURES = {
     "qot_batch_ptr": (_int, [_p, _i64, _i64, _p, _p]),
     "qot_embed_fwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
+    "qot_tconv_fwd_scores": (_int, [_p, _p, _p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
+                                    _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_fwd_tile": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _i64,

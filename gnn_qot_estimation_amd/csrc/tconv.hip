@@ -30,13 +30,19 @@ __device__ __forceinline__ float dotv(const float4 (&a)[NV], const float4 (&b)[N
 }
 __device__ __forceinline__ float comp4(const float4& a, int c) { return c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w)); }
 
-template <int H, int D>
+// MT (table mode, rowmap != NULL): the dense part of the logit, <q_i, k_j>, is entry (row_i, row_j) of the V x V matrix
+// Mtab = T_q T_k^T of the projected table (one small MFMA product per step, 4 MB at V = 1000: L2-resident) -- the lane that
+// prefetches an edge's source row looks it up, and the per-edge key-row gather, the H-term dot and its lane-group reduction
+// go; the value row is the only row gathered per edge.  (The tile form above computes rows of that matrix inside the
+// workgroup, which only pays for small V.)
+template <int H, int D, bool MT = false>
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v_,
     const float* __restrict__ skip, int ld, const float* __restrict__ ea,
     const float* __restrict__ we, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int32_t* __restrict__ rowmap,
-    float* __restrict__ out, float* __restrict__ stats, int64_t N, ActParams act) {
+    float* __restrict__ out, float* __restrict__ stats, int64_t N, ActParams act,
+    const float* __restrict__ Mtab = nullptr, int ldm = 0) {
     constexpr int CPL = tconv_cpl(H), NV = CPL / 4;
     constexpr int TPR = H / CPL;
     constexpr int RPB = 256 / TPR;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
     for (int base = beg; base < end; base += BT) {
         const int pme = base + sub;
         int myj = 0;
-        float mye[D];
+        float mye[D], mym = 0.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) mye[d] = 0.f;
         if (sub < BT && pme < end) {
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
             const int64_t e = eid[pme];
 #pragma unroll
             for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+            if (MT) mym = rs * Mtab[ri * ldm + myj];
         }
         const int cnt = (end - base < BT) ? end - base : BT;
         constexpr int UF = 4;            // source rows in flight per group (2 x UF x CPL registers)
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
                 const int64_t jr = (u0 + u < cnt) ? j : 0;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    kr[u][v] = ld4(k + jr * ld + c0 + 4 * v);
+                    if (!MT) kr[u][v] = ld4(k + jr * ld + c0 + 4 * v);
                     vr[u][v] = ld4(v_ + jr * ld + c0 + 4 * v);
                 }
             }
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(
                     float ee[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
-                    float s = group_sum<TPR>(dotv<NV>(qi, kr[u]));
+                    float s = MT ? __shfl(mym, u0 + u, TPR) : group_sum<TPR>(dotv<NV>(qi, kr[u]));
 #pragma unroll
                     for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
                     float mn = fmaxf(m, s);
@@ -704,6 +711,27 @@ extern "C" int qot_tconv_fwd(const float* q, const float* k, const float* v, con
         tconv_fwd_kernel<kH, kD><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
             q, k, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N,
             make_act(act, act_slope, act_p, act_seed, act_step));
+    }));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// Table mode with the score matrix (tconv_fwd_kernel<., ., MT>): scores[V, ld_scores] = T_q T_k^T (unscaled), rowmap = table
+// row of every node, col = table row of every in-edge's source.  k is not read.
+extern "C" int qot_tconv_fwd_scores(const float* q, const float* v, const float* skip, int ld, const float* scores,
+                                    int ld_scores, const float* edge_attr, const float* w_edge, const int32_t* rowptr,
+                                    const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out, float* stats,
+                                    int64_t N, int H, int D, int act, float act_slope, float act_p, uint64_t act_seed,
+                                    const int64_t* act_step, qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (N == 0) return QOT_OK;
+    if (!q || !v || !skip || !out || !stats || !w_edge || !scores || !rowmap || !col || (ld & 3) || ld_scores <= 0)
+        return QOT_ERR_BADARG;
+    QOT_DISPATCH_H(H, QOT_DISPATCH_D(D, {
+        constexpr int RPB = tconv_rpb(kH);
+        tconv_fwd_kernel<kH, kD, true><<<grid_for(N, RPB), 256, 0, (hipStream_t)stream>>>(
+            q, nullptr, v, skip, ld, edge_attr, w_edge, rowptr, col, eid, rowmap, out, stats, N,
+            make_act(act, act_slope, act_p, act_seed, act_step), scores, ld_scores);
     }));
     QOT_LAUNCH_CHECK();
     return QOT_OK;

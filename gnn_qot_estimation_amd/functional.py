@@ -250,6 +250,16 @@ def smooth_l1_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, beta: floa
 
 
 # ------------------------------------------------------------------ TransformerConv (a2)
+def tconv_scores_ok(qkvs: torch.Tensor, maps, num_nodes: int) -> bool:
+    """Table mode whose logits can come from the V x V score matrix ``T_q T_k^T`` (``qot_tconv_fwd_scores``): a table of
+    4 <= V <= 4096 rows (16 MB of scores at most: L2 / Infinity Cache resident), V % 4 == 0, H % 32 == 0, and enough
+    nodes that the V^2 H product is small next to the per-edge dots it replaces."""
+    if maps is None or os.environ.get("QOT_NO_TCONV_SCORES"):
+        return False
+    V, H = qkvs.shape[0], qkvs.shape[1] // 4
+    return 4 <= V <= 4096 and V % 4 == 0 and H % 32 == 0 and num_nodes >= 4 * V
+
+
 class TConvFn(torch.autograd.Function):
     """Fused edge-softmax-aggregate of TransformerConv on packed projections.
 
@@ -292,6 +302,15 @@ class TConvFn(torch.autograd.Function):
             _lib.call("qot_tconv_fwd_tile", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
                       P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
                       N, H, D, int(n_), int(B_), *_act_args(act))
+        elif tconv_scores_ok(qkvs, maps, N):
+            # table mode at large V: <q_i, k_j> looked up in T_q T_k^T (one small product on the matrix cores, L2-resident)
+            # instead of a key-row gather and an H-term dot per edge
+            V = qkvs.shape[0]
+            scores = torch.empty(V, V, dtype=torch.float32, device=qkvs.device)
+            _lib.call("qot_gemm_nt", _off(qkvs, 0), H4, _off(qkvs, H), H4, P(scores), V, V, V, H, None, None, None)
+            _lib.call("qot_tconv_fwd_scores", _off(qkvs, 0), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4, P(scores), V,
+                      P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
+                      N, H, D, *_act_args(act))
         else:
             _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
                       P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),

@@ -133,6 +133,14 @@ int qot_embed_bwd(const float* grad_out, const int32_t* ids, float* grad_table, 
  * rowmap[i] = table row of node i and `col` must then hold the table row of each in-edge's source
  * (node_ids[col]).  NULL: one row per node, as produced by a node-level GEMM.
  */
+/* qot_tconv_fwd in table mode with the logits' dense part <q_i, k_j> looked up in scores[V, ld_scores] = T_q T_k^T
+ * (unscaled; qot_gemm_nt on the projected table) instead of gathered and multiplied per edge: rowmap (required) = table row
+ * of every node, col = table row of every in-edge's source.  Same results up to the order of the H-term dot. */
+int qot_tconv_fwd_scores(const float* q, const float* v, const float* skip, int ld, const float* scores, int ld_scores,
+                         const float* edge_attr, const float* w_edge, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* eid, const int32_t* rowmap, float* out, float* stats, int64_t N, int H, int D,
+                         int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
+                         qot_stream_t stream);
 int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                   const float* edge_attr, const float* w_edge, const int32_t* rowptr,
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,

@@ -1153,4 +1153,5 @@ def test_tile_form_forward_is_taken_only_for_small_graphs(cuda_device, monkeypat
         with torch.no_grad():
             m(batch)
         assert ("qot_tconv_fwd_tile" in calls) == want_tile, (n, H, calls)
-        assert ("qot_tconv_fwd" in calls) != want_tile
+        # large tables: the plain form with its logits looked up in T_q T_k^T (qot_tconv_fwd_scores; N >= 4 V here)
+        assert ("qot_tconv_fwd_scores" in calls) != want_tile and "qot_tconv_fwd" not in calls

@@ -13,6 +13,10 @@ dev = torch.device("cuda:0")
 
 
 def run(name, model, batch, loss_fn, steps=10, warm=3):
+    # the per-graph index build's status word is read back once, after the timed steps (graph.CHECK_INDEX_STATUS: "a loop that
+    # must not synchronise per batch may set this False and call check_index_status once per epoch"); the first warm-up
+    # step still reads it at once
+    from gnn_qot_estimation_amd import graph as G
     model.to(dev).train()
     flat = FlatModel(model)
     opt = FusedSGD(flat, lr=0.01, momentum=0.9)
@@ -25,14 +29,17 @@ def run(name, model, batch, loss_fn, steps=10, warm=3):
         flat.gather_grads()
         opt.step()
         return loss
-    for _ in range(warm):
+    for w in range(warm):
         loss = step()
+        G.CHECK_INDEX_STATUS = False
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    G.CHECK_INDEX_STATUS = True
+    G.check_index_status(dev)
     lv = float(loss)
     assert lv == lv, "non-finite loss"
     row = dict(config=name, graphs=batch.num_graphs, nodes=batch.num_nodes, edges=batch.num_edges,
