@@ -8,6 +8,14 @@
 // MFMA (8 per 64 instead of 4 per 16) and half the global loads / LDS stores (16 + 16 per 256 instead of 8 + 8 per 64);
 // the library's own kernel for this shape is a 256 x 256 x 32 tile for the same reason.
 //
+// Measured negative (r04): the stages of all tiles as one branch-free stream (stage s + 1 -- also the next tile's first
+// -- loaded and stored while stage s is multiplied; rolling fragments, 48 registers; 8-row epilogue bands behind the stage
+// buffers, no barrier around the epilogue).  Left to the scheduler, the single big block had its global loads sunk next
+// to the LDS stores that consume them: 118 / 118 TFLOP/s (plain / BatchNorm prologue) against 128 / 125 for this file,
+// whose `if (!last)` branches keep the loads a stage ahead; with the interleave pinned by sched_group_barrier (2 MFMA :
+// 1 load, 4 MFMA : 1 LDS store, fragment reads as registers come free) the loads still stayed late: 101 / 114.  Kept:
+// the branchy loop.
+//
 // Reference sites as in gemm.hip: lightpath_training/models.py:13,30 (GATConv's projection) and its autograd under
 // lightpath_training/train.py:128.
 #include <cstdlib>
