@@ -45,6 +45,12 @@ SIGNATURES = {
     "qot_embed_bwd": (_int, [_p, _p, _p, _i64, _int, _int, _p]),
     "qot_tconv_fwd_scores": (_int, [_p, _p, _p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                                     _int, _f, _f, _u64, _p, _p]),
+    "qot_tconv_rows_supported": (_int, [_int, _int, _int]),
+    "qot_tconv_rows_npad": (_int, [_int]),
+    "qot_tconv_rows_ld": (_int, [_int, _int, _int]),
+    "qot_tconv_bwd_dst_rows": (_int, [_p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _f, _f, _u64, _p,
+                                      _int, _i64, _int, _p, _p, _int, _int, _p]),
+    "qot_tconv_bwd_src_rows": (_int, [_p, _p, _p, _p, _p, _int, _i64, _int, _p, _int, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_fwd_tile": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _int, _i64,
@@ -129,6 +135,7 @@ SIGNATURES = {
     "qot_step_advance": (_int, [_p, _p, _p]),
     "qot_gather3": (_int, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     "qot_gemm_nt": (_int, [_p, _i64, _p, _i64, _p, _i64, _i64, _int, _int, _p, _p, _p, _p]),
+    "qot_gemm_nt_planes": (_int, [_p, _i64, _p, _i64, _p, _i64, _int, _int, _int, _p]),
     "qot_gemm_tn_splits": (_int, [_int, _int, _i64]),
     "qot_gemm256_takes": (_int, [_i64, _int]),
     "qot_gemm_tn_planes": (_int, [_p, _i64, _p, _i64, _p, _int, _int, _i64, _int, _p, _p, _p]),

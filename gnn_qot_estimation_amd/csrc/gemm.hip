@@ -119,9 +119,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
                                                          const float* __restrict__ shift, const float* __restrict__ bias,
                                                          const float* __restrict__ att_src = nullptr,
                                                          const float* __restrict__ att_dst = nullptr,
-                                                         float* __restrict__ a_src = nullptr, float* __restrict__ a_dst = nullptr) {
+                                                         float* __restrict__ a_src = nullptr, float* __restrict__ a_dst = nullptr,
+                                                         int kslices = 1) {
     __shared__ __attribute__((aligned(16))) float4 lds[2][2][1024];       // [stage][operand][slot]
     mfma_acc_in_agprs();
+    // kslices > 1 (qot_gemm_nt_planes: few output tiles, long K): workgroup id = slice * tiles + tile multiplies the K range
+    // [slice * K / kslices, ...) into plane `slice` of C ([kslices][M][ldc]); the caller sums the planes in order
+    const int64_t tiles_all = (int64_t)((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
+    const int64_t bid = kslices > 1 ? (int64_t)blockIdx.x % tiles_all : (int64_t)blockIdx.x;
+    if (kslices > 1) {
+        const int64_t slice = (int64_t)blockIdx.x / tiles_all;
+        K /= kslices;
+        A += slice * K;
+        B += slice * K;
+        C += slice * M * ldc;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2: the column tiles of ONE row block
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
     int64_t rb;
     int ct;
     {
-        const int64_t id = blockIdx.x;
+        const int64_t id = bid;
         const int64_t full = (ntm / 8) * 8;                  // row blocks that split evenly over the XCDs
         if (id < full * ntn) {
             const int64_t xcd = id % 8, j = id / 8;
@@ -459,6 +471,23 @@ extern "C" int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t 
     return QOT_OK;
 }
 
+// qot_gemm_nt for FEW output tiles and a long inner dimension: Cpart[kslices][M, N], plane s = A[:, Ks] . B[:, Ks]^T over its
+// slice of K (K / kslices a multiple of 32); the caller sums the planes in order (QOT_ROLE_SUM_ROWS).
+extern "C" int qot_gemm_nt_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int64_t M, int N,
+                                  int K, int kslices, qot_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || kslices <= 0) return QOT_ERR_BADARG;
+    if (!A || !B || !Cpart) return QOT_ERR_BADARG;
+    if ((K % kslices) || ((K / kslices) % kGemmBK) || (N & 3) || (lda & 3) || (ldb & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+        ((uintptr_t)Cpart & 15))
+        return QOT_ERR_UNSUPPORTED;
+    const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN) * kslices;
+    if (tiles > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+    gemm_nt_kernel<false><<<(int)tiles, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, N, M, N, K, nullptr, nullptr, nullptr,
+                                                                     nullptr, nullptr, nullptr, nullptr, kslices);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 // qot_gemm_nt with GATConv's attention logits from the epilogue: N = heads * 128 (one output tile per head), att_src /
 // att_dst [heads * 128], a_src / a_dst [M, heads] (see gemm_nt_kernel<., LOGITS>)
 extern "C" int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
@@ -486,12 +515,12 @@ extern "C" int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, i
     return QOT_OK;
 }
 
-// split count of qot_gemm_tn for a [K, M]^T [K, N] product (enough workgroups to fill the part, chunks of >= 1024 rows)
+// split count of qot_gemm_tn for a [K, M]^T [K, N] product (enough workgroups to fill the part, chunks of >= 128 rows)
 extern "C" int qot_gemm_tn_splits(int M, int N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int64_t tiles = (int64_t)((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
     int64_t s = (4 * (int64_t)num_cus() + tiles - 1) / tiles;
-    const int64_t maxs = (K + 1023) / 1024;
+    const int64_t maxs = (K + 127) / 128;                    // chunks of >= 128 rows (four stages)
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 256) s = 256;

@@ -15,8 +15,9 @@ __device__ __forceinline__ void sort_row_keys(int32_t* __restrict__ k, int beg, 
 }
 
 
-__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
-    __shared__ int wsum[4];
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+    __shared__ int wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
 #pragma unroll
@@ -26,12 +27,17 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
     __syncthreads();
     return base + inc - v;
 }
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) { return block_exclusive_scan<256>(v, total); }
 
 
 // ---- block-diagonal batches: the whole index in ONE launch, one workgroup per graph ----------
@@ -42,16 +48,17 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
 // LDS ints: cin[n] cout[n] rp[n+1] rpt[n+1] | rank_in[m] rank_out[m] key_in[m] key_out[m] slot_of[m]
 //           ends[m] (local source << 16 | local destination: the edge list is read from HBM once) | lnid[n] (node ids)
 // status (optional): bit 0 set if an edge leaves its graph's node range (caller's slices are wrong).
+template <int NT>
 __device__ __forceinline__ void block_scan_into(const int* __restrict__ cnt, int* __restrict__ out, int n) {
-    // exclusive scan of cnt[0..n) into out[0..n], out[n] = total; all 256 threads call it
+    // exclusive scan of cnt[0..n) into out[0..n], out[n] = total; all NT threads call it
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 256) {
+    for (int c0 = 0; c0 < n; c0 += NT) {
         const int idx = c0 + threadIdx.x;
         const int v = idx < n ? cnt[idx] : 0;
         int total;
-        const int ex = block_exclusive_scan_256(v, &total);
+        const int ex = block_exclusive_scan<NT>(v, &total);
         const int carry = carry_s;
         if (idx < n) out[idx] = carry + ex;
         __syncthreads();
@@ -62,6 +69,9 @@ __device__ __forceinline__ void block_scan_into(const int* __restrict__ cnt, int
     __syncthreads();
 }
 
+// NT threads per workgroup: 256 inside the multi-role launch; 1024 in a launch of its own for graphs whose LDS image
+// leaves one workgroup per CU anyway (csr_by_graph_wide_kernel: every phase is a loop over the graph's edges or rows)
+template <int NT = 256>
 __device__ __forceinline__ void csr_by_graph_body(
     const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ node_ptr,
     const int64_t* __restrict__ edge_ptr, int64_t B, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
@@ -89,7 +99,7 @@ __device__ __forceinline__ void csr_by_graph_body(
     int64_t sj[2] = {0, 0}, si[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int e = threadIdx.x + 256 * u;
+        const int e = threadIdx.x + NT * u;
         if (e < m) { sj[u] = ei[e0 + e]; si[u] = ei[E + e0 + e]; }
     }
     int* cin = lds;
@@ -103,10 +113,10 @@ __device__ __forceinline__ void csr_by_graph_body(
     int* slot_of = key_out + cap_m;
     unsigned int* ends = reinterpret_cast<unsigned int*>(slot_of + cap_m);
     int* lnid = reinterpret_cast<int*>(ends + cap_m);          // the graph's node ids (table mode), read back in the slot loop
-    for (int t = threadIdx.x; t < n; t += 256) { cin[t] = 0; cout[t] = 0; }
+    for (int t = threadIdx.x; t < n; t += NT) { cin[t] = 0; cout[t] = 0; }
     if (node_ids) {
         if ((int)threadIdx.x < n) { ids32[n0 + threadIdx.x] = (int32_t)nid0; lnid[threadIdx.x] = (int)nid0; }
-        for (int t = threadIdx.x + 256; t < n; t += 256) {
+        for (int t = threadIdx.x + NT; t < n; t += NT) {
             const int v = (int)node_ids[n0 + t];
             ids32[n0 + t] = v;
             lnid[t] = v;
@@ -114,17 +124,17 @@ __device__ __forceinline__ void csr_by_graph_body(
     }
     __syncthreads();
     bool bad = false;
-    for (int ec = 0; ec < m; ec += 512) {
+    for (int ec = 0; ec < m; ec += 2 * NT) {
         if (ec > 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = ec + threadIdx.x + 256 * u;
+                const int e = ec + threadIdx.x + NT * u;
                 if (e < m) { sj[u] = ei[e0 + e]; si[u] = ei[E + e0 + e]; }
             }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int e = ec + threadIdx.x + 256 * u;
+            const int e = ec + threadIdx.x + NT * u;
             if (e < m) {
                 int j = (int)(sj[u] - n0), i = (int)(si[u] - n0);
                 if (i < 0 || i >= n || j < 0 || j >= n) { bad = true; i = i < 0 ? 0 : (i >= n ? n - 1 : i); j = j < 0 ? 0 : (j >= n ? n - 1 : j); }
@@ -136,9 +146,9 @@ __device__ __forceinline__ void csr_by_graph_body(
     }
     if (bad && status) atomicOr(status, 1);
     __syncthreads();
-    block_scan_into(cin, rp, n);
-    block_scan_into(cout, rpt, n);
-    for (int e = threadIdx.x; e < m; e += 256) {
+    block_scan_into<NT>(cin, rp, n);
+    block_scan_into<NT>(cout, rpt, n);
+    for (int e = threadIdx.x; e < m; e += NT) {
         const unsigned int ji = ends[e];
         key_in[rp[ji & 0xFFFFu] + rank_in[e]] = e;
         key_out[rpt[ji >> 16] + rank_out[e]] = e;
@@ -148,7 +158,7 @@ __device__ __forceinline__ void csr_by_graph_body(
     // take the row of every slot, so that the per-slot outputs can be written slot-parallel (coalesced)
     int* row_of = rank_in;
     int* row_of_t = rank_out;
-    for (int r = threadIdx.x; r < 2 * n; r += 256) {
+    for (int r = threadIdx.x; r < 2 * n; r += NT) {
         if (r < n) {
             const int beg = rp[r], end = rp[r + 1];
             sort_row_keys(key_in, beg, end);
@@ -165,7 +175,7 @@ __device__ __forceinline__ void csr_by_graph_body(
         }
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < m; p += 256) {
+    for (int p = threadIdx.x; p < m; p += NT) {
         const int key = key_in[p];
         const int lsrc = (int)(ends[key] >> 16);
         const int64_t src = n0 + (int64_t)lsrc;

@@ -16,6 +16,7 @@
 //                       gradient row sum}, stage 2 {table projection backward | lin_edge level-2 sum}
 //                                                                      -- seven launches before (functional.py)
 // Jobs inside one launch MUST be independent (no job may read what another job of the same launch writes).
+#include <cstdlib>
 #include "common.hpp"
 #include "graph_prep_dev.hpp"
 #include "mfma_tile.hpp"
@@ -246,6 +247,36 @@ static int plan_role(qot_role_t& r, int64_t* blocks, size_t* lds) {
     }
 }
 
+// The per-graph index build of LARGE graphs (LDS image above 64 KB: one workgroup per CU whatever its width) in a launch of
+// its own with 1024 threads per graph: every phase is a loop over the graph's edges or rows, and at 1000 nodes / 4000 edges
+// 256 threads walked each of them in 16 rounds (196 us for 1024 graphs at cfg4).
+__global__ __launch_bounds__(1024) void csr_by_graph_wide_kernel(
+    const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ edge_ptr, int64_t B, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+    int32_t* __restrict__ eid, int32_t* __restrict__ row, int32_t* __restrict__ rowptr_t, int32_t* __restrict__ col_t,
+    int32_t* __restrict__ pos_t, int32_t* __restrict__ eid_t, float* __restrict__ invdeg, int32_t* __restrict__ status,
+    int cap_n, int cap_m, const int64_t* __restrict__ node_ids, int32_t* __restrict__ ids32, int32_t* __restrict__ colf,
+    int32_t* __restrict__ colf_t, int32_t* __restrict__ ptr32) {
+    extern __shared__ int wide_lds[];
+    csr_by_graph_body<1024>(ei, E, N, node_ptr, edge_ptr, B, rowptr, col, eid, row, rowptr_t, col_t, pos_t, eid_t, invdeg, status,
+                            cap_n, cap_m, node_ids, ids32, colf, colf_t, ptr32, (int64_t)blockIdx.x, wide_lds);
+}
+constexpr size_t kCsrWideMinLds = 64 * 1024;
+
+static int launch_wide_csr(const qot_role_t& ro, int64_t blocks, size_t lds, hipStream_t stream) {
+    static size_t allowed[kMaxDevices];
+    const int lrc = ensure_dyn_lds(reinterpret_cast<const void*>(csr_by_graph_wide_kernel), lds, allowed);
+    if (lrc != QOT_OK) return lrc;
+    auto P = [&](int k) { return const_cast<void*>(ro.p[k]); };
+    csr_by_graph_wide_kernel<<<(int)blocks, 1024, lds, stream>>>(
+        (const int64_t*)P(0), ro.i[0], ro.i[1], (const int64_t*)P(1), (const int64_t*)P(2), ro.i[2], (int32_t*)P(3), (int32_t*)P(4),
+        (int32_t*)P(5), (int32_t*)P(6), (int32_t*)P(7), (int32_t*)P(8), (int32_t*)P(9), (int32_t*)P(10), (float*)P(11),
+        (int32_t*)P(12), (int)ro.i[3], (int)ro.i[4], (const int64_t*)P(13), (int32_t*)P(14), (int32_t*)P(15), (int32_t*)P(16),
+        (int32_t*)P(17));
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 // a table projection over >= kTableBlockMinV rows: its own launch (see table_project_*_block_kernel)
 static int launch_heavy_role(const qot_role_t& ro, int64_t blocks, size_t lds, hipStream_t stream) {
     const int V = (int)ro.i[0];
@@ -282,6 +313,11 @@ extern "C" int qot_run_roles(const qot_role_t* roles, int n_roles, qot_stream_t 
         if (rc != QOT_OK) return rc;
         if ((ro.kind == QOT_ROLE_TABLE_PROJECT_FWD || ro.kind == QOT_ROLE_TABLE_PROJECT_BWD) && table_rows_per_block(ro.i[0]) > 1) {
             const int hrc = launch_heavy_role(ro, blocks, need, stream);     // jobs of one call are independent: any order
+            if (hrc != QOT_OK) return hrc;
+            continue;
+        }
+        if (ro.kind == QOT_ROLE_CSR_BY_GRAPH && need > kCsrWideMinLds && !getenv("QOT_NO_WIDE_CSR")) {
+            const int hrc = launch_wide_csr(ro, blocks, need, stream);
             if (hrc != QOT_OK) return hrc;
             continue;
         }

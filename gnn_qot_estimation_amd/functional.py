@@ -196,7 +196,16 @@ class TableProjectFn(torch.autograd.Function):
         V, H = table.shape
         out = torch.empty(V, 4 * H, dtype=torch.float32, device=table.device)
         cnt, snap = step_pair if step_pair is not None else (None, None)
-        if group is not None and V > 0:
+        ctx.heavy = table_gemm_ok(V, H)
+        if ctx.heavy:
+            # a large table (cfg5: 1000 x 256): one product on the matrix cores instead of the blocked projection kernel
+            # (68 -> ~25 us); the dropout counter advances first, as inside that kernel
+            if cnt is not None:
+                _lib.call("qot_step_advance", P(cnt), P(snap))
+            w4 = torch.cat([wq, wk, wv, ws], 0)
+            b4 = torch.cat([bq, bk, bv, bs], 0)
+            _lib.call("qot_gemm_nt", P(table), H, P(w4), H, P(out), 4 * H, V, 4 * H, H, None, None, P(b4))
+        elif group is not None and V > 0:
             group.add(_lib.ROLE_TABLE_PROJECT_FWD, (table, wq, bq, wk, bk, wv, bv, ws, bs, out, cnt, snap), (V, H))
         else:
             _lib.call("qot_table_project_fwd", P(table), P(wq), P(bq), P(wk), P(bk), P(wv), P(bv), P(ws), P(bs), P(out),
@@ -213,7 +222,23 @@ class TableProjectFn(torch.autograd.Function):
         gt = torch.empty(V * H, dtype=torch.float32, device=dev)
         gw = torch.empty(4 * H * H, dtype=torch.float32, device=dev)
         gb = torch.empty(4 * H, dtype=torch.float32, device=dev)
-        if LG.enabled():
+        if ctx.heavy:
+            # large tables: grad_table = g W4 and grad_W = g^T table as split products on the matrix cores, planes summed in
+            # order in one launch (cfg5: 161 -> ~45 us for the blocked kernel's job)
+            if LG.enabled():
+                LG.flush()                                  # g may be a row sum still waiting in the epilogue
+            lib = _lib.load()
+            w4t = torch.cat([wq.t(), wk.t(), wv.t(), ws.t()], 1).contiguous()          # [H, 4H]
+            ks = 8
+            planes_t = torch.empty(ks, V * H, dtype=torch.float32, device=dev)
+            _lib.call("qot_gemm_nt_planes", P(g), 4 * H, P(w4t), 4 * H, P(planes_t), V, H, 4 * H, ks)
+            splits = lib.qot_gemm_tn_splits(4 * H, H, V)
+            planes_w = torch.empty(splits, 4 * H * H, dtype=torch.float32, device=dev)
+            _lib.call("qot_gemm_tn_planes", P(g), 4 * H, P(table), H, P(planes_w), 4 * H, H, V, splits, None, None)
+            _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (planes_t, gt), (ks, V * H, 0)),
+                            _lib.make_role(_lib.ROLE_SUM_ROWS, (planes_w, gw), (splits, 4 * H * H, 0))])
+            gb = colsum(g)
+        elif LG.enabled():
             # ``g`` (the table gradient) may itself be a deferred row sum of the TransformerConv backward: this job
             # rides in stage 2 of the backward epilogue, and the epilogue is launched now -- in table mode this node
             # is the last one of the pass
@@ -249,6 +274,13 @@ def smooth_l1_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, beta: floa
     return loss, grad
 
 
+def table_gemm_ok(V: int, H: int) -> bool:
+    """The embedding-table projection and its backward run as products on ``qot_gemm_nt`` / ``_planes`` / ``qot_gemm_tn_planes``
+    (V * H >= 1000 * 256: cfg5's table; at cfg4's 1000 x 128 the blocked one-kernel form of ``roles.hip`` measured the same
+    or better): that form is latency-bound there."""
+    return V * H >= 1000 * 256 and V % 4 == 0 and H % 32 == 0 and not os.environ.get("QOT_NO_TABLE_GEMM")
+
+
 # ------------------------------------------------------------------ TransformerConv (a2)
 def tconv_scores_ok(qkvs: torch.Tensor, maps, num_nodes: int) -> bool:
     """Table mode whose logits can come from the V x V score matrix ``T_q T_k^T`` (``qot_tconv_fwd_scores``): a table of
@@ -280,6 +312,7 @@ class TConvFn(torch.autograd.Function):
         # the table gradient may wait for the epilogue only when its consumer is TableProjectFn.backward (which flushes)
         ctx.table_from_project = type(qkvs.grad_fn).__name__ == "TableProjectFnBackward"
         qkvs, edge_attr, w_edge = _f32c(qkvs), _f32c(edge_attr), _f32c(w_edge)
+        ctx.scores = None
         H4 = qkvs.shape[1]
         H = H4 // 4
         D = w_edge.shape[1]
@@ -306,7 +339,7 @@ class TConvFn(torch.autograd.Function):
             # table mode at large V: <q_i, k_j> looked up in T_q T_k^T (one small product on the matrix cores, L2-resident)
             # instead of a key-row gather and an H-term dot per edge
             V = qkvs.shape[0]
-            scores = torch.empty(V, V, dtype=torch.float32, device=qkvs.device)
+            scores = ctx.scores = torch.empty(V, V, dtype=torch.float32, device=qkvs.device)
             _lib.call("qot_gemm_nt", _off(qkvs, 0), H4, _off(qkvs, H), H4, P(scores), V, V, V, H, None, None, None)
             _lib.call("qot_tconv_fwd_scores", _off(qkvs, 0), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4, P(scores), V,
                       P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
@@ -332,6 +365,8 @@ class TConvFn(torch.autograd.Function):
         N = graph.num_nodes
         dev = qkvs.device
         rowmap, colf, colf_t = (maps[0], maps[1], maps[2]) if maps is not None else (None, graph.col, None)
+        if ctx.scores is not None and tconv_rows_ok(qkvs, maps, H, D):
+            return _tconv_backward_rows(ctx, g, qkvs, edge_attr, w_edge, stats, y, act_step)
         escr = torch.empty(max(graph.cap, 1), 2, dtype=torch.float32, device=dev)
         delta = torch.empty(N, dtype=torch.float32, device=dev)
         pds = torch.empty(N, D, dtype=torch.float32, device=dev)
@@ -399,6 +434,98 @@ class TConvFn(torch.autograd.Function):
                     LG.flush()                                 # (rare: the concatenation below reads the row sum)
                 gq = torch.cat([gq, gq.new_zeros(qkvs.shape[0] - n, H4)], 0)
         return gq, None, gwe_flat.view(H, D), None, None, None
+
+
+def tconv_rows_ok(qkvs: torch.Tensor, maps, H: int, D: int) -> bool:
+    """The row form of the backward (``csrc/tconv_rows.hip``) takes this batch: table mode with ``node_ids == arange(n)`` in
+    every graph, the score matrix kept from the forward, a table of exactly those n rows."""
+    if maps is None or os.environ.get("QOT_NO_TCONV_ROWS"):
+        return False
+    B, n = maps[3]
+    return (B >= 1 and n == qkvs.shape[0] and bool(_lib.load().qot_tconv_rows_supported(int(n), int(H), int(D))))
+
+
+def _tconv_backward_rows(ctx, g, qkvs, edge_attr, w_edge, stats, y, act_step):
+    """``TConvFn.backward`` in the row form: destination pass (one workgroup per table row and slice of the graphs: grad M
+    row, grad P, grad T_skip), source pass (grad T_v), the slices summed in order, then grad T_q / grad T_k from two small
+    products on the matrix cores.  Returns what ``backward`` returns."""
+    graph, maps = ctx.graph, ctx.maps
+    lib = _lib.load()
+    dev = qkvs.device
+    H4 = qkvs.shape[1]
+    H = H4 // 4
+    D = w_edge.shape[1]
+    N = graph.num_nodes
+    B, n = maps[3]
+    colf = maps[1]
+    scores = ctx.scores
+    parts = int(max(1, min(B, 8)))
+    npad, ldrow = lib.qot_tconv_rows_npad(n), lib.qot_tconv_rows_ld(n, H, D)
+    f32 = dict(dtype=torch.float32, device=dev)
+    escr = torch.empty(max(graph.cap, 1), 2, **f32)
+    delta = torch.empty(N, **f32)
+    gskip = torch.empty(N, H, **f32)
+    drows = torch.empty(parts, n * ldrow, **f32)
+    wparts = torch.empty(parts * n, H * D, **f32)
+    vrows = torch.empty(parts, n * H, **f32)
+    if ctx.act is not None:
+        slope, p, seed = ctx.act
+        act_args = (P(y), float(slope), float(p if act_step is not None else 0.0), int(seed), P(act_step))
+    else:
+        act_args = (None, 0.0, 0.0, 0, None)
+    _lib.call("qot_tconv_bwd_dst_rows", P(g), _off(qkvs, 0), _off(qkvs, 2 * H), H4, P(edge_attr), P(w_edge), P(stats),
+              P(graph.rowptr), P(colf), P(graph.eid), P(scores), scores.shape[1], P(gskip), P(escr), P(delta), *act_args,
+              int(n), int(B), parts, P(drows), P(wparts), H, D)
+    _lib.call("qot_tconv_bwd_src_rows", P(gskip), P(escr), P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), int(n), int(B),
+              parts, P(vrows), H)
+    # the slices and the lin_edge partials, each summed in a fixed order (one multi-role launch); 32 floats of slack behind S:
+    # the product below reads K = npad + 32 columns from the grad M column on (its operand B is zero there)
+    S_buf = torch.zeros(n * ldrow + 32, **f32)
+    S = S_buf[:n * ldrow]
+    gv = torch.empty(n * H, **f32)
+    gwe_g = torch.empty(H * D, **f32)
+    roles = [_lib.make_role(_lib.ROLE_SUM_ROWS, (drows, S), (parts, n * ldrow, 0)),
+             _lib.make_role(_lib.ROLE_SUM_ROWS, (vrows, gv), (parts, n * H, 0))]
+    blocks = parts * n
+    two_level = blocks > 256
+    if two_level:
+        per = 128
+        groups = (blocks + per - 1) // per
+        level1 = torch.empty(groups, H * D, **f32)
+        roles.append(_lib.make_role(_lib.ROLE_SUM_ROWS, (wparts, level1), (blocks, H * D, per)))
+    else:
+        roles.append(_lib.make_role(_lib.ROLE_SUM_ROWS, (wparts, gwe_g), (blocks, H * D, 0)))
+    _lib.run_roles(roles)
+    S = S.view(n, ldrow)
+    rs = 1.0 / float(H) ** 0.5
+    gM = S[:, H:H + npad]                                   # [n, npad], columns >= n are zero
+    gP = S[:, H + npad:H + npad + D]                        # [n, D]
+    tq, tk = qkvs[:, 0:H], qkvs[:, H:2 * H]
+    # grad T_q = rs (grad M T_k + grad P W_e^T) as ONE product over K = npad + 32: A = [grad M | grad P | ...] (adjacent
+    # in S), B = rs [T_k^T | W_e | 0]; few output tiles, long K: split over K, planes summed in order
+    K1 = npad + 32
+    Bq = torch.zeros(H, K1, **f32)
+    Bq[:, :n] = tk.t()
+    Bq[:, npad:npad + D] = w_edge
+    Bq.mul_(rs)
+    ks = 8 if (K1 // 32) % 8 == 0 else (4 if (K1 // 32) % 4 == 0 else (3 if (K1 // 32) % 3 == 0 else 1))
+    planes_q = torch.empty(ks, n * H, **f32)
+    _lib.call("qot_gemm_nt_planes", P(gM), ldrow, P(Bq), K1, P(planes_q), n, H, K1, ks)
+    # grad T_k = rs grad M^T T_q: TN product (inner dimension = the n table rows), split over it
+    splits = lib.qot_gemm_tn_splits(npad, H, n)
+    planes_k = torch.empty(splits, npad * H, **f32)
+    _lib.call("qot_gemm_tn_planes", P(gM), ldrow, _off(qkvs, 0), H4, P(planes_k), npad, H, n, splits, None, None)
+    gq_, gk_ = torch.empty(n * H, **f32), torch.empty(npad * H, **f32)
+    roles = [_lib.make_role(_lib.ROLE_SUM_ROWS, (planes_q, gq_), (ks, n * H, 0)),
+             _lib.make_role(_lib.ROLE_SUM_ROWS, (planes_k, gk_), (splits, npad * H, 0))]
+    if two_level:
+        roles.append(_lib.make_role(_lib.ROLE_SUM_ROWS, (level1, gwe_g), (groups, H * D, 0)))
+    _lib.run_roles(roles)
+    g4 = torch.cat([gq_.view(n, H), gk_.view(npad, H)[:n] * rs, gv.view(n, H), S[:, 0:H]], dim=1)
+    # grad lin_edge = sum_i q_i/sqrt(H) (x) pd_i + g_i (x) p2_i; the first part is a function of the table row only
+    tqp = _small_gemm(tq, gP, None, H, D, n, 1, H4, ldrow, 1)          # T_q^T grad P: A(c, r) = tq[r, c], B(r, d) = gP[r, d]
+    gwe = torch.add(gwe_g.view(H, D), tqp, alpha=rs)
+    return g4, None, gwe, None, None, None
 
 
 def tconv_graph_plan(table, H: int, D: int, graph: GraphIndex, maps):

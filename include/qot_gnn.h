@@ -141,6 +141,27 @@ int qot_tconv_fwd_scores(const float* q, const float* v, const float* skip, int 
                          const int32_t* eid, const int32_t* rowmap, float* out, float* stats, int64_t N, int H, int D,
                          int act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step,
                          qot_stream_t stream);
+/* Row form of TransformerConv's backward in table mode for large tables (csrc/tconv_rows.hip; autograd of
+ * TransformerConv.propagate under loss.backward(), topological_training/train.py:115, with x = emb[node_ids],
+ * models.py:51-53, and node_ids == arange(n) in each of the B graphs, dataset.py:78): no per-node grad_q / grad_k --
+ * grad M[r_i, r_j] += ds_e on the score matrix of qot_tconv_fwd_scores, from which the caller forms
+ * grad T_q = (grad M T_k + grad P W_e^T) / sqrt(H) and grad T_k = grad M^T T_q / sqrt(H).
+ * qot_tconv_bwd_dst_rows: a workgroup owns table row r for one of `parts` slices of the graphs; leaves parts * n partial
+ * rows (row part * n + r) of qot_tconv_rows_ld(n, H, D) floats, [grad T_skip (H) | grad M (qot_tconv_rows_npad(n): n
+ * rounded up to 32, the tail zero) | grad P (D)], parts * n rows of H * D lin_edge partials (sum of g_i[c] p2_i[d]; the
+ * T_q part of that gradient is rs * T_q^T grad P), grad_skip [N, H] (gradient wrt the conv output behind the fused
+ * activation) and escr / delta for the source pass.  qot_tconv_bwd_src_rows: parts * n partial rows of grad T_v (H).
+ * The caller sums the `parts` row blocks in order.  H in {64, 128, 256}; qot_tconv_rows_supported(n, H, D). */
+int qot_tconv_rows_supported(int n, int H, int D);
+int qot_tconv_rows_npad(int n);
+int qot_tconv_rows_ld(int n, int H, int D);
+int qot_tconv_bwd_dst_rows(const float* grad_out, const float* q, const float* v, int ld, const float* edge_attr,
+                           const float* w_edge, const float* stats, const int32_t* rowptr, const int32_t* colf,
+                           const int32_t* eid, const float* scores, int ld_scores, float* grad_skip, float* escr, float* delta,
+                           const float* y_act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step, int n,
+                           int64_t B, int parts, float* part_rows, float* wedge_partials, int H, int D, qot_stream_t stream);
+int qot_tconv_bwd_src_rows(const float* grad_skip, const float* escr, const int32_t* rowptr_t, const int32_t* col_t,
+                           const int32_t* pos_t, int n, int64_t B, int parts, float* part_rows, int H, qot_stream_t stream);
 int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                   const float* edge_attr, const float* w_edge, const int32_t* rowptr,
                   const int32_t* col, const int32_t* eid, const int32_t* rowmap, float* out,
@@ -542,6 +563,10 @@ int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float*
 int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                        const float* scale, const float* shift, const float* bias, const float* att_src,
                        const float* att_dst, float* a_src, float* a_dst, qot_stream_t stream);
+/* qot_gemm_nt for few output tiles and a long inner dimension: Cpart[kslices][M, N], plane s = the product over the s-th
+ * slice of K (K / kslices a multiple of 32); the caller sums the planes in order (QOT_ROLE_SUM_ROWS). */
+int qot_gemm_nt_planes(const float* A, int64_t lda, const float* B, int64_t ldb, float* Cpart, int64_t M, int N, int K,
+                       int kslices, qot_stream_t stream);
 int qot_gemm_tn_splits(int M, int N, int64_t K);
 /* 1 when qot_gemm_nt / qot_gemm_nt_logits run a product of this size on the 256 x 256 x 32 tiles of csrc/gemm256.hip (one
  * persistent workgroup per CU; at least one tile per CU and N >= 256), 0 for the 128 x 128 tiles of csrc/gemm.hip.  Same
