@@ -1559,6 +1559,9 @@ class BnLinearFn(torch.autograd.Function):
         gz = _f32c(gz)
         N, C = x.shape
         if N == 0:
+            if synced:      # an empty shard still takes part in the statistics' all-reduce the other ranks are waiting in
+                dist, _ = _dist_world()
+                dist.all_reduce(torch.zeros(2 * C, dtype=torch.float64, device=x.device), op=dist.ReduceOp.SUM)
             return (torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(bias), None, None, None, None, None,
                     None, None, torch.zeros_like(lin_weight), None, None)
         gy = grad_x_product(gz, lin_weight)                  # [N, C]
