@@ -226,3 +226,23 @@ def test_small_linear_thin_output_weight_gradient_matches_fp64(cuda_device, m, k
     assert _rel(w.grad, gd.t() @ xd) <= 2e-5
     assert _rel(x.grad, gd @ wd) <= 1e-5
     assert _rel(b.grad, gd.sum(0)) <= 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(1000, 128, 1056, 3), (1000, 256, 1024, 8), (77, 64, 256, 4), (4099, 128, 64, 2)])
+def test_gemm_nt_planes_sum_to_the_product(cuda_device, M, N, K, ks):
+    """qot_gemm_nt_planes: few output tiles, long inner dimension -- plane s is the product over the s-th slice of K; the planes
+    summed in order give A B^T (grad T_q of the row form, the table projection's grad_table)."""
+    from gnn_qot_estimation_amd import _lib
+    torch.manual_seed(6)
+    dev = cuda_device
+    A, B = torch.randn(M, K + 32, device=dev), torch.randn(N, K, device=dev)       # A: a column slice of a wider matrix
+    planes = torch.full((ks, M * N), float("nan"), device=dev)
+    _lib.call("qot_gemm_nt_planes", A, K + 32, B, K, planes, M, N, K, ks)
+    out = torch.empty(M * N, device=dev)
+    _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (planes, out), (ks, M * N, 0))])
+    ref = A[:, :K].double() @ B.double().t()
+    assert _rel(out.view(M, N), ref) <= 1e-5
+    per = K // ks
+    assert _rel(planes[1].view(M, N), A[:, per:2 * per].double() @ B[:, per:2 * per].double().t()) <= 1e-5
+    with pytest.raises(_lib.QotError):                      # a slice that is not a whole number of 32-deep stages
+        _lib.call("qot_gemm_nt_planes", A, K + 32, B, K, planes, M, N, K, ks + 5)
