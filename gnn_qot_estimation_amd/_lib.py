@@ -50,6 +50,8 @@ SIGNATURES = {
     "qot_tconv_rows_ld": (_int, [_int, _int, _int]),
     "qot_tconv_bwd_dst_rows": (_int, [_p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _f, _f, _u64, _p,
                                       _int, _i64, _int, _p, _p, _int, _int, _p]),
+    "qot_tconv_fwd_rows": (_int, [_p, _p, _p, _int, _p, _int, _p, _p, _p, _p, _p, _p, _p, _int, _i64, _int, _int, _int,
+                                  _int, _f, _f, _u64, _p, _p]),
     "qot_tconv_bwd_src_rows": (_int, [_p, _p, _p, _p, _p, _int, _i64, _int, _p, _int, _p]),
     "qot_tconv_fwd": (_int, [_p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int,
                              _int, _f, _f, _u64, _p, _p]),

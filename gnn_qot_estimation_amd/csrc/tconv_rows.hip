@@ -358,6 +358,139 @@ __global__ __launch_bounds__(256) void tconv_bwd_src_rows_kernel(
     }
 }
 
+// Forward in the row form: the workgroup that owns table row r for a slice of the graphs stages row r of M once and holds
+// q_r W_e and the skip row in registers; per destination only the edge list, the edge features and the value rows are read
+// (tconv_fwd_kernel<., ., MT> reads the query and skip rows and looks M up in L2 for every destination), and the next
+// graph's edge range is requested one graph ahead.  Same arithmetic, same order: bit-equal outputs.
+template <int H, int D>
+__global__ __launch_bounds__(256) void tconv_fwd_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ v_, const float* __restrict__ skip, int ld,
+    const float* __restrict__ ea, const float* __restrict__ we, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ colf, const int32_t* __restrict__ eid, const float* __restrict__ Mtab, int ldm,
+    float* __restrict__ out, float* __restrict__ stats, int tile_n, int64_t tile_B, int parts, ActParams act) {
+    constexpr int CPL = trows_cpl(), NV = CPL / 4;
+    constexpr int TPR = H / CPL;
+    constexpr int RPB = 256 / TPR;
+    extern __shared__ float sh[];
+    float* sM = sh;
+    const int npad = trows_npad(tile_n);
+    const int sub = threadIdx.x % TPR, rloc = threadIdx.x / TPR;
+    const int vb = blockIdx.x;
+    const int r = vb / parts, part = vb % parts;
+    const int64_t per = (tile_B + parts - 1) / parts;
+    const int64_t b0 = (int64_t)part * per;
+    const int64_t b1 = (b0 + per < tile_B) ? b0 + per : tile_B;
+    const float rs = rsqrtf((float)H);
+    const int c0 = CPL * sub;
+    for (int t = threadIdx.x; t < npad; t += 256) sM[t] = t < tile_n ? rs * Mtab[(int64_t)r * ldm + t] : 0.f;
+    float4 qi[NV], sk[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        qi[v] = scale4(rs, ld4(q + (int64_t)r * ld + c0 + 4 * v));
+        sk[v] = ld4(skip + (int64_t)r * ld + c0 + 4 * v);
+    }
+    float wl[CPL][D];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int d = 0; d < D; ++d) wl[c][d] = we[(c0 + c) * D + d];
+    float qe[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t = fmaf(trows_comp(qi[c >> 2], c & 3), wl[c][d], t);
+        qe[d] = group_sum<TPR>(t);
+    }
+    __syncthreads();
+    constexpr int BT = (TPR < 16) ? TPR : 16;
+    int nbeg = 0, nend = 0;
+    if (b0 + rloc < b1) {
+        const int64_t i0 = (b0 + rloc) * tile_n + r;
+        nbeg = rowptr[i0];
+        nend = rowptr[i0 + 1];
+    }
+    for (int64_t b = b0 + rloc; b < b1; b += RPB) {
+        const int64_t i = b * tile_n + r;
+        const int beg = nbeg, end = nend;
+        if (b + RPB < b1) {
+            const int64_t in_ = (b + RPB) * tile_n + r;
+            nbeg = rowptr[in_];
+            nend = rowptr[in_ + 1];
+        }
+        float m = -INFINITY, l = 0.f;
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f4zero();
+        float aacc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) aacc[d] = 0.f;
+        for (int base = beg; base < end; base += BT) {
+            const int pme = base + sub;
+            int myj = 0;
+            float mye[D], mym = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) mye[d] = 0.f;
+            if (sub < BT && pme < end) {
+                myj = colf[pme];
+                const int64_t e = eid[pme];
+#pragma unroll
+                for (int d = 0; d < D; ++d) mye[d] = ea[e * D + d];
+                mym = sM[myj];
+            }
+            const int cnt = (end - base < BT) ? end - base : BT;
+            constexpr int UF = 4;
+            for (int u0 = 0; u0 < cnt; u0 += UF) {
+                float4 vr[UF][NV];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    const int64_t j = __shfl(myj, u0 + u, TPR);
+                    const int64_t jr = (u0 + u < cnt) ? j : 0;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) vr[u][v] = ld4(v_ + jr * ld + c0 + 4 * v);
+                }
+#pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    if (u0 + u < cnt) {                           // group-uniform
+                        float ee[D];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) ee[d] = __shfl(mye[d], u0 + u, TPR);
+                        float s = __shfl(mym, u0 + u, TPR);
+#pragma unroll
+                        for (int d = 0; d < D; ++d) s = fmaf(qe[d], ee[d], s);
+                        const float mn = fmaxf(m, s);
+                        const float sc = __expf(m - mn);
+                        const float pe = __expf(s - mn);
+                        l = fmaf(l, sc, pe);
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) acc[v] = fma4(pe, vr[u][v], scale4(sc, acc[v]));
+#pragma unroll
+                        for (int d = 0; d < D; ++d) aacc[d] = fmaf(pe, ee[d], aacc[d] * sc);
+                        m = mn;
+                    }
+                }
+            }
+        }
+        const float denom = l + 1e-16f;
+        const float inv = 1.0f / denom;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 o = scale4(inv, acc[v]);
+            float oc[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < D; ++d) oc[c] = fmaf(wl[4 * v + c][d], aacc[d] * inv, oc[c]);
+            st4(out + i * H + c0 + 4 * v, act_apply4(make_float4(oc[0] + sk[v].x, oc[1] + sk[v].y, oc[2] + sk[v].z, oc[3] + sk[v].w),
+                                                     act, (uint64_t)(i * H + c0 + 4 * v) >> 2));
+        }
+        if (sub == 0) {
+            stats[2 * i] = (beg < end) ? m : 0.f;
+            stats[2 * i + 1] = denom;
+        }
+    }
+}
+
 }  // namespace qot
 
 using namespace qot;
@@ -427,6 +560,33 @@ extern "C" int qot_tconv_bwd_src_rows(const float* grad_skip, const float* escr,
     if (H == 64) tconv_bwd_src_rows_kernel<64><<<n * parts, 256, 0, stream>>>(grad_skip, escr, rowptr_t, col_t, pos_t, n, B, parts, part_rows);
     else if (H == 128) tconv_bwd_src_rows_kernel<128><<<n * parts, 256, 0, stream>>>(grad_skip, escr, rowptr_t, col_t, pos_t, n, B, parts, part_rows);
     else tconv_bwd_src_rows_kernel<256><<<n * parts, 256, 0, stream>>>(grad_skip, escr, rowptr_t, col_t, pos_t, n, B, parts, part_rows);
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+// Forward of the row form: out / stats as qot_tconv_fwd_scores (bit-equal), node_ids == arange(n) in each of the B graphs.
+extern "C" int qot_tconv_fwd_rows(const float* q, const float* v, const float* skip, int ld, const float* scores, int ld_scores,
+                                  const float* edge_attr, const float* w_edge, const int32_t* rowptr, const int32_t* colf,
+                                  const int32_t* eid, float* out, float* stats, int n, int64_t B, int parts, int H, int D, int act,
+                                  float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step, qot_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || B <= 0 || parts <= 0 || parts > B) return QOT_ERR_BADARG;
+    if (!q || !v || !skip || !scores || !edge_attr || !w_edge || !rowptr || !colf || !eid || !out || !stats || (ld & 3) ||
+        ld_scores < n)
+        return QOT_ERR_BADARG;
+    if (!qot_tconv_rows_supported(n, H, D) || (int64_t)n * parts > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
+    const ActParams ap = make_act(act, act_slope, act_p, act_seed, act_step);
+    const size_t lds = (size_t)trows_npad(n) * sizeof(float);
+    if (lds > 64 * 1024) return QOT_ERR_UNSUPPORTED;
+#define QOT_TROWS_F(HH)                                                                                              \
+    if (H == HH) {                                                                                                   \
+        QOT_DISPATCH_D(D, {                                                                                          \
+            tconv_fwd_rows_kernel<HH, kD><<<n * parts, 256, lds, stream>>>(q, v, skip, ld, edge_attr, w_edge, rowptr, colf, eid, \
+                                                                           scores, ld_scores, out, stats, n, B, parts, ap);      \
+        });                                                                                                          \
+    }
+    QOT_TROWS_F(64) QOT_TROWS_F(128) QOT_TROWS_F(256)
+#undef QOT_TROWS_F
     QOT_LAUNCH_CHECK();
     return QOT_OK;
 }

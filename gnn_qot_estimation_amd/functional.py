@@ -341,9 +341,16 @@ class TConvFn(torch.autograd.Function):
             V = qkvs.shape[0]
             scores = ctx.scores = torch.empty(V, V, dtype=torch.float32, device=qkvs.device)
             _lib.call("qot_gemm_nt", _off(qkvs, 0), H4, _off(qkvs, H), H4, P(scores), V, V, V, H, None, None, None)
-            _lib.call("qot_tconv_fwd_scores", _off(qkvs, 0), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4, P(scores), V,
-                      P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
-                      N, H, D, *_act_args(act))
+            if tconv_rows_ok(qkvs, maps, H, D) and not os.environ.get("QOT_NO_TCONV_FWD_ROWS"):
+                # node_ids == arange(n) in every graph: a workgroup per table row and slice of the graphs (csrc/tconv_rows.hip)
+                B_, n_ = maps[3]
+                _lib.call("qot_tconv_fwd_rows", _off(qkvs, 0), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4, P(scores), V,
+                          P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(out), P(stats), int(n_), int(B_),
+                          int(max(1, min(B_, 8))), H, D, *_act_args(act))
+            else:
+                _lib.call("qot_tconv_fwd_scores", _off(qkvs, 0), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4, P(scores), V,
+                          P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),
+                          N, H, D, *_act_args(act))
         else:
             _lib.call("qot_tconv_fwd", _off(qkvs, 0), _off(qkvs, H), _off(qkvs, 2 * H), _off(qkvs, 3 * H), H4,
                       P(edge_attr), P(w_edge), P(graph.rowptr), P(colf), P(graph.eid), P(rowmap), P(out), P(stats),

@@ -160,6 +160,12 @@ int qot_tconv_bwd_dst_rows(const float* grad_out, const float* q, const float* v
                            const int32_t* eid, const float* scores, int ld_scores, float* grad_skip, float* escr, float* delta,
                            const float* y_act, float act_slope, float act_p, uint64_t act_seed, const int64_t* act_step, int n,
                            int64_t B, int parts, float* part_rows, float* wedge_partials, int H, int D, qot_stream_t stream);
+/* forward of the row form: out / stats bit-equal to qot_tconv_fwd_scores; a workgroup owns table row r for one of `parts`
+ * slices of the B graphs (row r of the score matrix staged once, q_r W_e and the skip row in registers) */
+int qot_tconv_fwd_rows(const float* q, const float* v, const float* skip, int ld, const float* scores, int ld_scores,
+                       const float* edge_attr, const float* w_edge, const int32_t* rowptr, const int32_t* colf, const int32_t* eid,
+                       float* out, float* stats, int n, int64_t B, int parts, int H, int D, int act, float act_slope, float act_p,
+                       uint64_t act_seed, const int64_t* act_step, qot_stream_t stream);
 int qot_tconv_bwd_src_rows(const float* grad_skip, const float* escr, const int32_t* rowptr_t, const int32_t* col_t,
                            const int32_t* pos_t, int n, int64_t B, int parts, float* part_rows, int H, qot_stream_t stream);
 int qot_tconv_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,

@@ -1153,5 +1153,5 @@ def test_tile_form_forward_is_taken_only_for_small_graphs(cuda_device, monkeypat
         with torch.no_grad():
             m(batch)
         assert ("qot_tconv_fwd_tile" in calls) == want_tile, (n, H, calls)
-        # large tables: the plain form with its logits looked up in T_q T_k^T (qot_tconv_fwd_scores; N >= 4 V here)
-        assert ("qot_tconv_fwd_scores" in calls) != want_tile and "qot_tconv_fwd" not in calls
+        # large tables: logits looked up in T_q T_k^T, a workgroup per table row (qot_tconv_fwd_rows; N >= 4 V here)
+        assert ("qot_tconv_fwd_rows" in calls) != want_tile and "qot_tconv_fwd" not in calls

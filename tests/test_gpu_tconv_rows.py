@@ -36,8 +36,8 @@ def test_scores_forward_and_row_form_backward_equal_the_per_destination_kernels(
         out.square().sum().backward()
         monkeypatch.setattr(_lib, "call", real)
         res[mode] = (out.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters()}, calls)
-    assert "qot_tconv_fwd_scores" in res["rows"][2] and "qot_tconv_bwd_dst_rows" in res["rows"][2]
-    assert "qot_tconv_fwd_scores" not in res["plain"][2] and "qot_tconv_bwd_dst" in res["plain"][2]
+    assert "qot_tconv_fwd_rows" in res["rows"][2] and "qot_tconv_bwd_dst_rows" in res["rows"][2]
+    assert "qot_tconv_fwd_rows" not in res["plain"][2] and "qot_tconv_bwd_dst" in res["plain"][2]
     if p == 0.0:                       # (with dropout the two runs draw different masks: the step counter advances)
         assert _close(res["rows"][0], res["plain"][0])
         for k, g in res["rows"][1].items():
@@ -61,3 +61,21 @@ def test_row_form_backward_is_bitwise_reproducible(cuda_device):
         grads.append([p_.grad.clone() for p_ in model.parameters()])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_row_form_forward_is_bit_equal_to_the_per_destination_scores_kernel(cuda_device, monkeypatch):
+    """qot_tconv_fwd_rows stages the score row, q_r W_e and the skip row once per workgroup; same arithmetic in the same order
+    as tconv_fwd_kernel<., ., MT>: identical outputs (dropout on: same counter, same mask)."""
+    import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import synthetic as S
+    dev = cuda_device
+    batch = S.topological_batch(5, 7, n=1000).to(dev)
+    torch.manual_seed(2)
+    model = q.TopologicalGNN(1000, 128, 3, 4, dropout_p=0.0).to(dev).eval()
+    outs = []
+    for off in ("", "1"):
+        monkeypatch.setenv("QOT_NO_TCONV_FWD_ROWS", off) if off else monkeypatch.delenv("QOT_NO_TCONV_FWD_ROWS", raising=False)
+        batch._qot_cache = {}
+        with torch.no_grad():
+            outs.append(model(batch).clone())
+    assert torch.equal(outs[0], outs[1])
