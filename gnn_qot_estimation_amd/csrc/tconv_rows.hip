@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256, (D <= 4 && H <= 128) ? 4 : 3) void tconv_bwd_d
         float s = pred[0][threadIdx.x];
         for (int r2 = 1; r2 < RPB; ++r2) s += pred[r2][threadIdx.x];
         out[H + npad + threadIdx.x] = s;
+    } else if ((int)threadIdx.x < ldrow - H - npad) {
+        out[H + npad + threadIdx.x] = 0.f;                 // the row's padding: the caller's product reads across it
     }
 #pragma unroll
     for (int d0 = 0; d0 < D; d0 += DCH) {

@@ -485,9 +485,11 @@ def _tconv_backward_rows(ctx, g, qkvs, edge_attr, w_edge, stats, y, act_step):
               int(n), int(B), parts, P(drows), P(wparts), H, D)
     _lib.call("qot_tconv_bwd_src_rows", P(gskip), P(escr), P(graph.rowptr_t), P(graph.col_t), P(graph.pos_t), int(n), int(B),
               parts, P(vrows), H)
-    # the slices and the lin_edge partials, each summed in a fixed order (one multi-role launch); 32 floats of slack behind S:
-    # the product below reads K = npad + 32 columns from the grad M column on (its operand B is zero there)
-    S_buf = torch.zeros(n * ldrow + 32, **f32)
+    # the slices and the lin_edge partials, each summed in a fixed order (one multi-role launch); K1 floats of slack behind S:
+    # the product below reads K1 >= npad + 32 columns from the grad M column on (its operand B is zero past grad P: the
+    # columns it meets there -- the row's zero padding, the next row's head -- are finite)
+    K1 = 32 * (((npad // 32) + 1 + 7) // 8 * 8)            # grad M, grad P and padding up to eight equal K slices
+    S_buf = torch.zeros(n * ldrow + K1, **f32)
     S = S_buf[:n * ldrow]
     gv = torch.empty(n * H, **f32)
     gwe_g = torch.empty(H * D, **f32)
@@ -509,13 +511,12 @@ def _tconv_backward_rows(ctx, g, qkvs, edge_attr, w_edge, stats, y, act_step):
     gP = S[:, H + npad:H + npad + D]                        # [n, D]
     tq, tk = qkvs[:, 0:H], qkvs[:, H:2 * H]
     # grad T_q = rs (grad M T_k + grad P W_e^T) as ONE product over K = npad + 32: A = [grad M | grad P | ...] (adjacent
-    # in S), B = rs [T_k^T | W_e | 0]; few output tiles, long K: split over K, planes summed in order
-    K1 = npad + 32
+    # in S), B = rs [T_k^T | W_e | 0]; few output tiles, long K: eight K slices, planes summed in order
     Bq = torch.zeros(H, K1, **f32)
     Bq[:, :n] = tk.t()
     Bq[:, npad:npad + D] = w_edge
     Bq.mul_(rs)
-    ks = 8 if (K1 // 32) % 8 == 0 else (4 if (K1 // 32) % 4 == 0 else (3 if (K1 // 32) % 3 == 0 else 1))
+    ks = 8
     planes_q = torch.empty(ks, n * H, **f32)
     _lib.call("qot_gemm_nt_planes", P(gM), ldrow, P(Bq), K1, P(planes_q), n, H, K1, ks)
     # grad T_k = rs grad M^T T_q: TN product (inner dimension = the n table rows), split over it

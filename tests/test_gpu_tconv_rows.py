@@ -12,14 +12,15 @@ def _close(a, b, tol=2e-4):
     return float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6)
 
 
-@pytest.mark.parametrize("n,e,H,B,p", [(1000, 4000, 128, 8, 0.0), (1000, 4000, 256, 5, 0.0), (600, 1800, 64, 9, 0.5)])
-def test_scores_forward_and_row_form_backward_equal_the_per_destination_kernels(cuda_device, monkeypatch, n, e, H, B, p):
+@pytest.mark.parametrize("n,e,H,B,p,D", [(1000, 4000, 128, 8, 0.0, 4), (1000, 4000, 256, 5, 0.0, 4), (600, 1800, 64, 9, 0.5, 4),
+                                         (500, 1500, 128, 9, 0.0, 6), (300, 900, 64, 13, 0.0, 1)])
+def test_scores_forward_and_row_form_backward_equal_the_per_destination_kernels(cuda_device, monkeypatch, n, e, H, B, p, D):
     import gnn_qot_estimation_amd as q
     from gnn_qot_estimation_amd import _lib, synthetic as S
     dev = cuda_device
-    batch = S.topological_batch(4, B, n=n, e=e).to(dev)
+    batch = S.topological_batch(4, B, n=n, e=e, edge_dim=D).to(dev)
     torch.manual_seed(0)
-    model = q.TopologicalGNN(n, H, 3, 4, dropout_p=p).to(dev).train()
+    model = q.TopologicalGNN(n, H, 3, D, dropout_p=p).to(dev).train()
     res = {}
     for mode in ("rows", "plain"):
         calls = []
@@ -41,7 +42,14 @@ def test_scores_forward_and_row_form_backward_equal_the_per_destination_kernels(
     if p == 0.0:                       # (with dropout the two runs draw different masks: the step counter advances)
         assert _close(res["rows"][0], res["plain"][0])
         for k, g in res["rows"][1].items():
-            assert _close(g, res["plain"][1][k]), k
+            ref = res["plain"][1][k]
+            if k.endswith("lin_key.bias"):
+                # analytically zero (a constant added to every key of a destination leaves its softmax alone): both paths hold
+                # rounding noise there -- compared on the scale of the key weight's gradient
+                scale = float(res["plain"][1][k.replace("bias", "weight")].abs().max())
+                assert float((g - ref).abs().max()) <= 2e-4 * scale, k
+            else:
+                assert _close(g, ref), k
 
 
 def test_row_form_backward_is_bitwise_reproducible(cuda_device):
