@@ -85,9 +85,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
             acc[v] = f4zero();
         }
         const int beg = rowptr[i], end = rowptr[i + 1];
-        // EB in-edges in flight per lane group: two where a lane holds one float4 of the row, one where it already
-        // holds several (wide rows: the extra registers would cost resident waves)
-        constexpr int EB = (G::NV == 1) ? 2 : 1;
+        // EB in-edges in flight per lane group: their source ids are requested together, then their rows together.  r04: four
+        // for every width (wide rows had one: a destination of LightpathGNN's chain graphs -- three in-edges with the self loop
+        // -- then cost seven dependent round trips instead of three): 788 -> 743 us per layer at cfg3.  The same batching in
+        // the two backward passes measured WORSE (729 -> 826, 823 -> 844 us: they run at 4-5 TB/s of counter traffic, and the
+        // batch's padding slots re-read rows): they keep one edge at a time.
+        constexpr int EB = 4;
         for (int p = beg; p < end; p += EB) {
             int64_t jj[EB];
             float4 zz[EB][G::NV];
