@@ -458,7 +458,9 @@ extern "C" int qot_gemm_nt(const float* A, int64_t lda, const float* B, int64_t 
     if ((K % kGemmBK) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
         ((uintptr_t)C & 15) || ((uintptr_t)bias & 15))
         return QOT_ERR_UNSUPPORTED;
-    if (qot_gemm256_takes(M, N))
+    // (the 256 x 256 kernel addresses its operands with 32-bit byte offsets)
+    const bool fits32 = (uint64_t)M * (uint64_t)lda * 4 < (1ull << 32) && (uint64_t)N * (uint64_t)ldb * 4 < (1ull << 32);
+    if (qot_gemm256_takes(M, N) && fits32)
         return gemm256_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias, nullptr, nullptr, nullptr, nullptr,
                                  (hipStream_t)stream);
     const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
@@ -500,7 +502,8 @@ extern "C" int qot_gemm_nt_logits(const float* A, int64_t lda, const float* B, i
     if ((K % kGemmBK) || (N % kGemmBN) || (lda & 3) || (ldb & 3) || (ldc & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
         ((uintptr_t)C & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)att_src & 15) || ((uintptr_t)att_dst & 15))
         return QOT_ERR_UNSUPPORTED;
-    if (qot_gemm256_takes(M, N) && N <= 1024)
+    if (qot_gemm256_takes(M, N) && N <= 1024 && (uint64_t)M * (uint64_t)lda * 4 < (1ull << 32) &&
+        (uint64_t)N * (uint64_t)ldb * 4 < (1ull << 32))
         return gemm256_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, scale, shift, bias, att_src, att_dst, a_src, a_dst,
                                  (hipStream_t)stream);
     const int64_t tiles = ((M + kGemmBM - 1) / kGemmBM) * (N / kGemmBN);

@@ -8,14 +8,6 @@
 // MFMA (8 per 64 instead of 4 per 16) and half the global loads / LDS stores (16 + 16 per 256 instead of 8 + 8 per 64);
 // the library's own kernel for this shape is a 256 x 256 x 32 tile for the same reason.
 //
-// Measured negative (r04): the stages of all tiles as one branch-free stream (stage s + 1 -- also the next tile's first
-// -- loaded and stored while stage s is multiplied; rolling fragments, 48 registers; 8-row epilogue bands behind the stage
-// buffers, no barrier around the epilogue).  Left to the scheduler, the single big block had its global loads sunk next
-// to the LDS stores that consume them: 118 / 118 TFLOP/s (plain / BatchNorm prologue) against 128 / 125 for this file,
-// whose `if (!last)` branches keep the loads a stage ahead; with the interleave pinned by sched_group_barrier (2 MFMA :
-// 1 load, 4 MFMA : 1 LDS store, fragment reads as registers come free) the loads still stayed late: 101 / 114.  Kept:
-// the branchy loop.
-//
 // Reference sites as in gemm.hip: lightpath_training/models.py:13,30 (GATConv's projection) and its autograd under
 // lightpath_training/train.py:128.
 #include <cstdlib>
@@ -36,29 +28,48 @@ __device__ int g_gemm256_variant;  // ablation bits of the NT kernel (tools/benc
 #define G2_VAR(bit) 0
 #endif
 
-struct G2Frag { float4 a[4], b[4]; };
+// Fragments of a wave: a[i] (its four 32-row bands), b[2][j] (its four 32-column bands, current and next k group).  A k
+// group's 64 MFMAs run band by band (i-major), so a[i] is dead after its 16 MFMAs and takes the NEXT group's fragment at
+// once: 48 fragment registers instead of 64 for two full sets.
+struct G2Frag { float4 a[4], b[2][4]; };
 
 // float4 slot of (k group g of 8, half hi, row): lane (hi, r) of an MFMA reads slot (2g + hi) * 256 + (row ^ 2g) --
 // any constant XOR keeps the 16-lane groups of a ds_read_b128 on 16 distinct slots of one aligned block -- and the 8-lane
 // groups of the ds_write_b128 (four k groups of two neighbouring rows) land on 8 distinct slots mod 8.
 __device__ __forceinline__ int g2_slot(int g, int hi, int row) { return (2 * g + hi) * 256 + (row ^ (g << 1)); }
 
-__device__ __forceinline__ void g2_read_frag(G2Frag& f, const float4* __restrict__ As, const float4* __restrict__ Bs, int g,
-                                             int wm, int wn, int hi, int r31) {
+__device__ __forceinline__ float4 g2_read_a(const float4* __restrict__ As, int g, int i, int wm, int hi, int r31) {
+    return As[g2_slot(g, hi, wm * 128 + i * 32 + r31)];
+}
+__device__ __forceinline__ void g2_read_b(float4 (&b)[4], const float4* __restrict__ Bs, int g, int wn, int hi, int r31) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.a[i] = As[g2_slot(g, hi, wm * 128 + i * 32 + r31)];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) f.b[j] = Bs[g2_slot(g, hi, wn * 128 + j * 32 + r31)];
+    for (int j = 0; j < 4; ++j) b[j] = Bs[g2_slot(g, hi, wn * 128 + j * 32 + r31)];
 }
 
-// 64 MFMAs of one k group: 16 independent accumulators per k pair
-__device__ __forceinline__ void g2_group_mfma(const G2Frag& f, f32x16 (&c)[4][4]) {
+// 16 MFMAs of band i of one k group: four accumulators take turns
+__device__ __forceinline__ void g2_band_mfma(const float4& a, const float4 (&b)[4], f32x16 (&c)[4]) {
 #define QOT_STEP(COMP)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i].COMP, f.b[j].COMP, c[i][j], 0, 0, 0);
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        c[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.COMP, b[j].COMP, c[j], 0, 0, 0);
     QOT_STEP(x) QOT_STEP(y) QOT_STEP(z) QOT_STEP(w)
 #undef QOT_STEP
+}
+
+// k group G (compile-time 0..3) of the stage in (As, Bs): its 64 MFMAs; the fragments of the group after it -- group G + 1
+// of the same stage, or group 0 of (An, Bn) behind group 3 -- are read as registers come free.  SKIP: diagnostic build.
+template <int G>
+__device__ __forceinline__ void g2_group(G2Frag& f, const float4* __restrict__ As, const float4* __restrict__ Bs,
+                                         const float4* __restrict__ An, const float4* __restrict__ Bn, int wm, int wn, int hi,
+                                         int r31, f32x16 (&c)[4][4], bool skip_reads) {
+    constexpr int NG = (G + 1) & 3;
+    const float4* Ar = G == 3 ? An : As;
+    const float4* Br = G == 3 ? Bn : Bs;
+    if (!skip_reads) g2_read_b(f.b[(G + 1) & 1], Br, NG, wn, hi, r31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        g2_band_mfma(f.a[i], f.b[G & 1], c[i]);
+        if (!skip_reads) f.a[i] = g2_read_a(Ar, NG, i, wm, hi, r31);
+    }
 }
 
 __device__ __forceinline__ void g2_zero(f32x16 (&c)[4][4]) {
@@ -96,7 +107,23 @@ __device__ __forceinline__ void g2_band_out(float* __restrict__ reg, const f32x1
 // ---- NT: C[M, N] = A'[M, K] . B[N, K]^T (+ bias), persistent over the output tiles ------------------------------
 // Workgroup (xcd = id % 8, slot = id / 8) walks the tiles q = slot, slot + per_x, ... of ITS XCD: row block 8 (q / ntn)
 // + xcd, column tile q % ntn -- the column tiles of a row block run side by side on one XCD (one HBM fetch of the A
-// rows).  The first stage of the next tile is requested before the epilogue of the current one.
+// rows).
+// The stages of all its tiles form ONE stream: while stage s is multiplied, stage s + 1 -- the next 32 k of the tile or
+// the first 32 k of the next tile -- is loaded and stored to the other LDS buffer, so a tile boundary costs no pipeline
+// refill.  The loop body has no branch: one scheduling region of 192 MFMAs, 24 fragment reads, 16 (20) global loads and
+// 16 LDS stores whose interleave is pinned with sched_group_barrier: with ONE wave per SIMD nothing else fills the matrix
+// pipe while a clump of loads / stores / reads issues (an LDS store takes 13-26 issue cycles; the branchy first version
+// of this kernel had them in clumps of 8 between runs of ~60 MFMAs: 4-7 % on the diagnostic build's ablations, 128 / 125
+// TFLOP/s plain / BatchNorm prologue).  The operands come through BUFFER loads (one descriptor per matrix, 32-bit byte
+// offsets, the k offset in the scalar offset field): this compiler's sched_group_barrier VMEM masks do not match
+// global_load (a FLAT instruction) -- with global loads the same pins left them next to the LDS stores that consume them
+// (101 / 114 TFLOP/s), and without pins the scheduler sinks them there as well (118 / 118).  With buffer loads the pins
+// hold: 133-136 / 128-131 TFLOP/s (the library's plain product: 135).  Matrices above 4 GB take the 128 x 128 kernel.
+// The epilogue stages 8-row bands through 4 KB of LDS per wave BEHIND the stage buffers (they hold the next tile's first
+// stage by then) and needs no workgroup barrier.
+constexpr int kG2BandFloats = 8 * 128;                    // per wave
+constexpr size_t kG2BandBytes = (size_t)4 * kG2BandFloats * sizeof(float);
+
 template <bool AFFINE, bool LOGITS>
 __global__ __launch_bounds__(256) void gemm256_nt_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                          int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t M, int N,
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm256_nt_kernel(const float* __restrict
                                                          const float* __restrict__ shift, const float* __restrict__ bias,
                                                          const float* __restrict__ att_src, const float* __restrict__ att_dst,
                                                          float* __restrict__ a_src, float* __restrict__ a_dst) {
-    extern __shared__ __attribute__((aligned(16))) float4 g2lds[];       // [stage][operand][slot], then the attention vectors
+    extern __shared__ __attribute__((aligned(16))) float4 g2lds[];       // [stage][operand][slot] | bands | attention vectors
     mfma_acc_in_agprs();
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
@@ -115,7 +142,8 @@ __global__ __launch_bounds__(256) void gemm256_nt_kernel(const float* __restrict
     int64_t rb = (q / ntn) * 8 + xcd;
     int ct = (int)(q % ntn);
     if (rb >= ntm) return;
-    float* att = reinterpret_cast<float*>(g2lds + 4 * kG2Stage4);
+    float* band = reinterpret_cast<float*>(g2lds + 4 * kG2Stage4) + wave * kG2BandFloats;
+    float* att = reinterpret_cast<float*>(g2lds + 4 * kG2Stage4) + 4 * kG2BandFloats;
     if (LOGITS) {                                          // att_src | att_dst of all heads (N <= 1024: host side)
         for (int u = t; u < N; u += 256) {
             att[u] = att_src[u];
@@ -123,32 +151,39 @@ __global__ __launch_bounds__(256) void gemm256_nt_kernel(const float* __restrict
         }
     }
     const int gk = t & 3, row0 = t >> 2;                   // my k group; my rows: row0 + 64 j
-    const float* ap[4];
-    const float* bp[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AFFINE ? scale : A), 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AFFINE ? shift : A), 0, 0xFFFFFFFF, 0x00020000);
+    unsigned int ao[4], bo[4];                             // byte offsets of my rows (host side: M * lda * 4 < 2^32)
     auto point = [&](int64_t rb_, int ct_) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t ar = rb_ * kG2T + row0 + 64 * j;
             const int br = ct_ * kG2T + row0 + 64 * j;
-            ap[j] = A + (ar < M ? ar : M - 1) * lda + 8 * gk;          // clamped, not zeroed: see gemm_nt_kernel
-            bp[j] = B + (int64_t)(br < N ? br : N - 1) * ldb + 8 * gk;
+            ao[j] = (unsigned int)(((ar < M ? ar : M - 1) * lda + 8 * gk) * 4);          // clamped, not zeroed
+            bo[j] = (unsigned int)((((int64_t)(br < N ? br : N - 1)) * ldb + 8 * gk) * 4);
         }
     };
-    // The A half of a stage is in flight under k groups 0-1 and stored behind them, the B half under groups 2-3: 32
-    // prefetch registers instead of 64 (with both halves in flight at once the affine / logits forms spilled), and
-    // half a stage -- 128 MFMAs, 3.4 us -- is still several memory latencies.
+    auto bld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned int voff, int soff) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    // The A half of the next stage is in flight under k group 0 and stored under group 1, the B half (W rows: L2 hits) in
+    // flight under group 1 and stored under group 2: the two halves never hold registers at the same time.
     float4 pa[4][2], pb[4][2], ps[2], pt[2];
     auto load_a = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pa[j][0] = ld4(ap[j] + k0); pa[j][1] = ld4(ap[j] + k0 + 4); }
+        for (int j = 0; j < 4; ++j) { pa[j][0] = bld(ra, ao[j], 4 * k0); pa[j][1] = bld(ra, ao[j] + 16, 4 * k0); }
         if (AFFINE) {
-            ps[0] = ld4(scale + k0 + 8 * gk); ps[1] = ld4(scale + k0 + 8 * gk + 4);
-            pt[0] = ld4(shift + k0 + 8 * gk); pt[1] = ld4(shift + k0 + 8 * gk + 4);
+            ps[0] = bld(rsc, 32u * gk, 4 * k0); ps[1] = bld(rsc, 32u * gk + 16, 4 * k0);
+            pt[0] = bld(rsh, 32u * gk, 4 * k0); pt[1] = bld(rsh, 32u * gk + 16, 4 * k0);
         }
     };
     auto load_b = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pb[j][0] = ld4(bp[j] + k0); pb[j][1] = ld4(bp[j] + k0 + 4); }
+        for (int j = 0; j < 4; ++j) { pb[j][0] = bld(rbd, bo[j], 4 * k0); pb[j][1] = bld(rbd, bo[j] + 16, 4 * k0); }
     };
     auto stash_a = [&](int s) {
         float4* As = g2lds + (2 * s) * kG2Stage4;
@@ -177,102 +212,141 @@ __global__ __launch_bounds__(256) void gemm256_nt_kernel(const float* __restrict
     const int g2_var = g_gemm256_variant;
 #endif
     f32x16 c[4][4];
-    G2Frag f0, f1;
+    G2Frag f;
     point(rb, ct);
     load_a(0);
     load_b(0);
     stash_a(0);
     stash_b(0);
     __syncthreads();
+    g2_read_b(f.b[0], g2lds + kG2Stage4, 0, wn, hi, r31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = g2_read_a(g2lds, 0, i, wm, hi, r31);
     int cur = 0;
-    for (;;) {
+    int64_t nrb = rb;
+    int nct = ct;
+    bool have_next = true;
+    // scheduling masks of sched_group_barrier
+#define QOT_M(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0);
+#define QOT_V(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0);
+#define QOT_D(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+#define QOT_W(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0);
+    for (;;) {                                             // tiles
         g2_zero(c);
-        const float4* As = g2lds + (2 * cur) * kG2Stage4;
-        g2_read_frag(f0, As, As + kG2Stage4, 0, wm, wn, hi, r31);
-        if (G2_VAR(16)) f1 = f0;
-        int64_t nrb = 0;
-        int nct = 0;
-        bool have_next = false;
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool last = kt + 1 == nk;
-            const int kn = last ? 0 : (kt + 1) * kG2BK;
-            if (last) {                                    // the next tile's first stage, under this stage and the epilogue
-                q += per_x;
-                nrb = (q / ntn) * 8 + xcd;
-                nct = (int)(q % ntn);
-                have_next = nrb < ntm;
-                if (have_next) point(nrb, nct);
-            }
-            const bool more = !last || have_next;
-            if (more && !G2_VAR(1)) load_a(kn);
-            As = g2lds + (2 * cur) * kG2Stage4;
-            if (!G2_VAR(16)) g2_read_frag(f1, As, As + kG2Stage4, 1, wm, wn, hi, r31);
-            g2_group_mfma(f0, c);
-            if (!G2_VAR(16)) g2_read_frag(f0, As, As + kG2Stage4, 2, wm, wn, hi, r31);
-            g2_group_mfma(f1, c);
-            if (!last && !G2_VAR(2)) stash_a(cur ^ 1);     // (the last stage keeps its halves in registers over the epilogue:
-            if (more && !last && !G2_VAR(1)) load_b(kn);   //  only the A half fits there, the B half is requested after it)
-            if (!G2_VAR(16)) g2_read_frag(f1, As, As + kG2Stage4, 3, wm, wn, hi, r31);
-            g2_group_mfma(f0, c);
-            if (!last) {
-                if (!G2_VAR(2)) stash_b(cur ^ 1);
-                if (!G2_VAR(4)) lds_barrier();
-                cur ^= 1;
-                As = g2lds + (2 * cur) * kG2Stage4;
-                if (!G2_VAR(16)) g2_read_frag(f0, As, As + kG2Stage4, 0, wm, wn, hi, r31);
-            }
-            g2_group_mfma(f1, c);
+        for (int kt = 0; kt < nk; ++kt) {                  // stages
+        // the stage that is loaded while this one is multiplied
+        int kn = kt + 1;
+        if (kn == nk) {
+            kn = 0;
+            q += per_x;
+            nrb = (q / ntn) * 8 + xcd;
+            nct = (int)(q % ntn);
+            have_next = nrb < ntm;
+            if (have_next) point(nrb, nct);                // (none left: the loads below re-read this tile's first stage,
+        }                                                  //  the copy is never multiplied -- no branch in the body)
+        const float4* As = g2lds + (2 * cur) * kG2Stage4;
+        const float4* Bs = As + kG2Stage4;
+        const float4* An = g2lds + (2 * (cur ^ 1)) * kG2Stage4;
+        const float4* Bn = An + kG2Stage4;
+        const bool skip = G2_VAR(16);
+        if (!G2_VAR(1)) load_a(kn * kG2BK);
+        g2_group<0>(f, As, Bs, An, Bn, wm, wn, hi, r31, c, skip);
+        if (!G2_VAR(2)) stash_a(cur ^ 1);
+        if (!G2_VAR(1)) load_b(kn * kG2BK);
+        g2_group<1>(f, As, Bs, An, Bn, wm, wn, hi, r31, c, skip);
+        if (!G2_VAR(2)) stash_b(cur ^ 1);
+        g2_group<2>(f, As, Bs, An, Bn, wm, wn, hi, r31, c, skip);
+#ifndef QOT_G2_NO_PIN
+        // group 0: 8 (12) global loads of the A half
+        QOT_M(2) QOT_V(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_V(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_D(1) QOT_D(1)
+        QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) QOT_D(1)
+        if (AFFINE) { QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) QOT_M(4) QOT_V(1) } else { QOT_M(16) }
+        QOT_D(1) QOT_M(16) QOT_D(1)
+        // group 1: 8 LDS stores of the A half, then the 8 global loads of the B half
+        QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_D(1)
+        QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_D(1)
+        QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1)
+        QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1) QOT_M(2) QOT_V(1) QOT_D(1)
+        QOT_M(16) QOT_D(1)
+        // group 2: 8 LDS stores of the B half
+        QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_W(1) QOT_M(2) QOT_D(1) QOT_D(1)
+        QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_M(4) QOT_W(1) QOT_D(1)
+        QOT_M(16) QOT_D(1) QOT_M(16) QOT_D(1)
+#endif
+        if (!G2_VAR(4)) lds_barrier();
+        g2_group<3>(f, As, Bs, An, Bn, wm, wn, hi, r31, c, skip);
+#ifndef QOT_G2_NO_PIN
+        QOT_M(4) QOT_D(1) QOT_M(4) QOT_D(1) QOT_M(4) QOT_D(1) QOT_M(4) QOT_D(1) QOT_D(1)
+        QOT_M(16) QOT_D(1) QOT_M(16) QOT_D(1) QOT_M(16) QOT_D(1)
+#endif
+        cur ^= 1;
         }
-        // ---- epilogue: both stage buffers are free once every wave is past its last fragment read ----
-        lds_barrier();
-        float* reg = reinterpret_cast<float*>(g2lds) + wave * 4096;
+        // ---- the tile is complete: 16 bands of 8 rows per wave through the wave's own LDS ----
         const int64_t m0 = rb * kG2T + wm * 128;
         const int n0 = ct * kG2T + wn * 128;
-#pragma unroll                                   // c[i] must stay a register array: i is a compile-time constant per copy
-        for (int i = 0; i < 4; ++i) {
-            g2_band_out(reg, c, i, hi, r31, lane, [&](int pm, int q4, float4 v) {
-                const int64_t row = m0 + i * 32 + pm;
-                const int col = n0 + 4 * q4;
-                if (row < M && col < N) {
-                    if (bias) v = add4(v, ld4(bias + col));
-                    if (!G2_VAR(8) || v.x == 12345.678f) st4(C + row * ldc + col, v);
-                }
-            });
-            if (LOGITS) {
-                // the wave's 128 columns are ONE attention head (see gemm_nt_kernel<., LOGITS>): lane = (row pm, half)
-                const int pm = lane >> 1, half = lane & 1;
-                const int64_t row = m0 + i * 32 + pm;
-                float s_ = 0.f, d_ = 0.f;
-                if (n0 < N) {
-#pragma unroll 2                                 // fully unrolled, the 64 loads of a lane are hoisted together: spills
-                    for (int u = 0; u < 16; ++u) {
-                        const int cq = 64 * half + 4 * u;
-                        float4 v = ld4(reg + pm * 128 + (cq ^ ((pm & 7) << 2)));
-                        if (bias) v = add4(v, ld4(bias + n0 + cq));
-                        s_ += dot4(v, ld4(att + n0 + cq));
-                        d_ += dot4(v, ld4(att + 1024 + n0 + cq));
+#pragma unroll                                   // c[i][.][4 qd + rr] must stay register-indexed: constants per copy
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int pm = rr + 4 * hi;           // MFMA row (rr + 8 qd + 4 hi) of tile i = row pm of band (i, qd)
+                        const int pn = j * 32 + r31;
+                        band[pm * 128 + (pn ^ (pm << 2))] = c[i][j][4 * qd + rr];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int64_t rbase = m0 + i * 32 + 8 * qd;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int pm = idx >> 5, q4 = idx & 31;
+                    float4 v = ld4(band + pm * 128 + ((4 * q4) ^ (pm << 2)));
+                    const int64_t row = rbase + pm;
+                    const int col = n0 + 4 * q4;
+                    if (row < M && col < N) {
+                        if (bias) v = add4(v, ld4(bias + col));
+                        if (!G2_VAR(8) || v.x == 12345.678f) st4(C + row * ldc + col, v);
                     }
                 }
-                s_ += dpp_move<0xB1>(s_);              // quad_perm [1,0,3,2]: lane ^ 1
-                d_ += dpp_move<0xB1>(d_);
-                if (half == 0 && row < M && n0 < N) {
-                    const int heads = N / 128;
-                    a_src[row * heads + n0 / 128] = s_;
-                    a_dst[row * heads + n0 / 128] = d_;
+                if (LOGITS) {
+                    // the wave's 128 columns are ONE attention head (see gemm_nt_kernel<., LOGITS>): lane = (row pm, 16 columns)
+                    const int pm = lane >> 3, part = lane & 7;
+                    const int64_t row = rbase + pm;
+                    float s_ = 0.f, d_ = 0.f;
+                    if (n0 < N) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int cq = 16 * part + 4 * u;
+                            float4 v = ld4(band + pm * 128 + (cq ^ (pm << 2)));
+                            if (bias) v = add4(v, ld4(bias + n0 + cq));
+                            s_ += dot4(v, ld4(att + n0 + cq));
+                            d_ += dot4(v, ld4(att + 1024 + n0 + cq));
+                        }
+                    }
+                    s_ = group_sum<8>(s_);
+                    d_ = group_sum<8>(d_);
+                    if (part == 0 && row < M && n0 < N) {
+                        const int heads = N / 128;
+                        a_src[row * heads + n0 / 128] = s_;
+                        a_dst[row * heads + n0 / 128] = d_;
+                    }
                 }
+                asm volatile("" ::: "memory");
             }
-        }
         if (!have_next) break;
-        lds_barrier();                                     // the bands are read: the stage buffers may be written again
         rb = nrb;
         ct = nct;
-        cur = 0;
-        load_b(0);                                         // W rows: L2 hits
-        stash_a(0);
-        stash_b(0);
-        lds_barrier();
     }
+#undef QOT_M
+#undef QOT_V
+#undef QOT_D
+#undef QOT_W
 }
 
 }  // namespace qot
@@ -297,7 +371,7 @@ int gemm256_nt_launch(const float* A, int64_t lda, const float* B, int64_t ldb, 
     static size_t allowed[4][kMaxDevices];
     const bool logits = att_src != nullptr;
     if (logits && N > 1024) return QOT_ERR_UNSUPPORTED;
-    const size_t lds = kG2StageBytes + (logits ? kG2AttFloats * sizeof(float) : 0);
+    const size_t lds = kG2StageBytes + kG2BandBytes + (logits ? kG2AttFloats * sizeof(float) : 0);
     const int64_t tiles = ((M + kG2T - 1) / kG2T) * ((N + kG2T - 1) / kG2T);
     int64_t grid = num_cus();
     if (grid > tiles) grid = tiles;
