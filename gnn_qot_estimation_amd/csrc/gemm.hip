@@ -432,6 +432,147 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
     }
 }
 
+// The same product when EVERY stage is full (K a multiple of 32: cfg3's 707 008 rows): the loop body without a branch
+// (the stage after the last one re-reads it; the copy is never multiplied), operands through buffer loads and the
+// interleave pinned with sched_group_barrier as in gemm256.hip -- left to the scheduler the fragment reads sat one or two
+// MFMAs in front of their use (`ds_read2; s_waitcnt lgkmcnt(0)` before every group of six).
+template <bool AFFINE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_full_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              float* __restrict__ Cpart, int M, int N, int64_t K,
+                                                              int64_t kchunk, int nsplit, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][32 * 128];     // [stage][operand][k][column']
+    mfma_acc_in_agprs();
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hi = lane >> 5, r31 = lane & 31;
+    const int ntn = (N + kGemmBN - 1) / kGemmBN, ntm = (M + kGemmBM - 1) / kGemmBM;
+    const int tiles = ntn * ntm;
+    int split, tile_id;
+    {
+        const int id = blockIdx.x;
+        const int full = (nsplit / 8) * 8;
+        if (id < full * tiles) {
+            const int xcd = id % 8, j = id / 8;
+            split = xcd + 8 * (j / tiles);
+            tile_id = j % tiles;
+        } else {
+            const int j = id - full * tiles;
+            split = full + j / tiles;
+            tile_id = j % tiles;
+        }
+    }
+    const int m0 = (tile_id / ntn) * kGemmBM, n0 = (tile_id % ntn) * kGemmBN;
+    const int64_t kbeg = (int64_t)split * kchunk;
+    const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int q = t & 31, kr = 4 * (t >> 5);
+    const int ca = (m0 + 4 * q + 3 < M) ? m0 + 4 * q : M - 4;
+    const int cb = (n0 + 4 * q + 3 < N) ? n0 + 4 * q : N - 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+    if (AFFINE) { sc = ld4(scale + cb); sh = ld4(shift + cb); }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xFFFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xFFFFFFFF, 0x00020000);
+    unsigned int oa[4], ob[4];                           // byte offsets inside a stage (host side: K * ld * 4 < 2^32)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        oa[s] = (unsigned int)(((kr + s) * lda + ca) * 4);
+        ob[s] = (unsigned int)(((kr + s) * ldb + cb) * 4);
+    }
+    auto bld = [&](const __amdgpu_buffer_rsrc_t& r, unsigned int voff, unsigned int soff) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    float4 pa[4], pb[4];
+    auto load = [&](int64_t k0) {
+        const unsigned int sa = (unsigned int)(k0 * lda * 4), sb = (unsigned int)(k0 * ldb * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            pa[s] = bld(ra, oa[s], sa);
+            pb[s] = bld(rb, ob[s], sb);
+        }
+    };
+    auto stash = [&](int st) {
+        if (AFFINE) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pb[s] = affine_relu4<true>(pb[s], sc, sh);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st4(&lds[st][0][tn_dword(kr + s, 4 * q)], pa[s]);
+            st4(&lds[st][1][tn_dword(kr + s, 4 * q)], pb[s]);
+        }
+    };
+    f32x16 c[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+    const int64_t nk = (kend - kbeg) / kGemmBK;           // whole stages only (host side)
+    if (nk > 0) {
+        load(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    TnFrag f0, f1;
+    if (nk > 0) tn_read_frag(f0, lds[0][0], lds[0][1], 0, wm, wn, hi, r31);
+#define QOT_M(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0);
+#define QOT_V(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0);
+#define QOT_D(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+#define QOT_W(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0);
+#pragma unroll 1
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        const int64_t kn = (kt + 1 < nk) ? kt + 1 : kt;
+        load(kbeg + kn * kGemmBK);
+        tn_read_frag(f1, lds[cur][0], lds[cur][1], 1, wm, wn, hi, r31);
+        tn_pair_mfma(f0, c);
+        tn_read_frag(f0, lds[cur][0], lds[cur][1], 2, wm, wn, hi, r31);
+        tn_pair_mfma(f1, c);
+        tn_read_frag(f1, lds[cur][0], lds[cur][1], 3, wm, wn, hi, r31);
+        tn_pair_mfma(f0, c);
+        tn_read_frag(f0, lds[cur][0], lds[cur][1], 4, wm, wn, hi, r31);
+        tn_pair_mfma(f1, c);
+        tn_read_frag(f1, lds[cur][0], lds[cur][1], 5, wm, wn, hi, r31);
+        tn_pair_mfma(f0, c);
+        stash(cur ^ 1);
+        tn_read_frag(f0, lds[cur][0], lds[cur][1], 6, wm, wn, hi, r31);
+        tn_pair_mfma(f1, c);
+        tn_read_frag(f1, lds[cur][0], lds[cur][1], 7, wm, wn, hi, r31);
+        tn_pair_mfma(f0, c);
+        // quads 0-1: the eight loads of the next stage; quads 5-6: its eight LDS stores; a quad's four fragment reads
+        // under the MFMAs of the quad before it
+        QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1)
+        QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1) QOT_M(2) QOT_V(1) QOT_D(1)
+        QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1)
+        QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1)
+        QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1) QOT_M(2) QOT_W(1) QOT_D(1)
+        lds_barrier();
+        tn_read_frag(f0, lds[cur ^ 1][0], lds[cur ^ 1][1], 0, wm, wn, hi, r31);
+        tn_pair_mfma(f1, c);
+        QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1) QOT_M(2) QOT_D(1)
+    }
+#undef QOT_M
+#undef QOT_V
+#undef QOT_D
+#undef QOT_W
+    float* Cp = Cpart + (int64_t)split * M * N;
+    float* tile = &lds[0][0][0];
+    gemm_tile_to_lds(tile, c, wm, wn, hi, r31);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + t;
+        const int pm = idx >> 5, q4 = idx & 31;
+        const int row = m0 + pm, col = n0 + 4 * q4;
+        if (row < M && col < N) st4(Cp + (int64_t)row * N + col, ld4(tile + pm * 128 + ((4 * q4) ^ ((pm & 7) << 2))));
+    }
+}
+
 }  // namespace qot
 
 using namespace qot;
@@ -543,7 +684,14 @@ extern "C" int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, i
     kchunk = (kchunk + kGemmBK - 1) / kGemmBK * kGemmBK;
     const int64_t grid = (int64_t)((N + kGemmBN - 1) / kGemmBN) * ((M + kGemmBM - 1) / kGemmBM) * splits;
     if (grid > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
-    if (scale)
+    // every stage full and 32-bit byte offsets: the branch-free, pinned form
+    const bool full = (K % kGemmBK) == 0 && (uint64_t)K * (uint64_t)lda * 4 < (1ull << 32) &&
+                      (uint64_t)K * (uint64_t)ldb * 4 < (1ull << 32) && !getenv("QOT_NO_GEMM_TN_FULL");
+    if (full && scale)
+        gemm_tn_full_kernel<true><<<(int)grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, M, N, K, kchunk, splits, scale, shift);
+    else if (full)
+        gemm_tn_full_kernel<false><<<(int)grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, M, N, K, kchunk, splits, nullptr, nullptr);
+    else if (scale)
         gemm_tn_split_kernel<true><<<(int)grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, M, N, K, kchunk, splits, scale, shift);
     else
         gemm_tn_split_kernel<false><<<(int)grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, M, N, K, kchunk, splits, nullptr, nullptr);

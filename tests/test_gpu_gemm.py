@@ -36,8 +36,9 @@ def test_gemm_nt_matches_fp64(cuda_device, M, N, K, affine):
 
 
 # the last two: ragged chunk ends, ragged M / N at a long K
+# (K a multiple of 32: the branch-free, pinned kernel gemm_tn_full_kernel; else the general one)
 @pytest.mark.parametrize("M,N,K", [(512, 512, 5000), (128, 512, 33), (512, 128, 100000), (4, 8, 7), (512, 512, 70001),
-                                   (260, 388, 66000)])
+                                   (260, 388, 66000), (260, 388, 64000), (512, 512, 9600), (128, 128, 32)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_gemm_tn_planes_sum_to_the_product(cuda_device, M, N, K, affine):
     from gnn_qot_estimation_amd import _lib
