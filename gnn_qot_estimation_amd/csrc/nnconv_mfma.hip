@@ -236,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void nnconv_mfma64_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = 0.f;
     int ch = 0;
+    // (r04, measured: the A fragment of group L + 1 read from LDS before the four MFMAs of group L instead of right in front
+    //  of its use -- `ds_read_b128; s_waitcnt lgkmcnt(0)` before every group as it stands -- 96.0 -> 96.9 us: no gain, not kept)
 #pragma unroll 1
     for (; ch + NB <= NCH; ch += NB) {
 #pragma unroll
