@@ -416,7 +416,7 @@ def lightpath_measurement(device, steps):
     alg_flops = 3.0 * fwd_flops - 2.0 * N * W * F_
     # the dominant kernels of this step, alone: the forward projection with the previous layer's BatchNorm + ReLU in its
     # operand load and the attention logits in its epilogue (gemm256_nt_kernel<true, true>: the top entry of
-    # profiles/r04_cfg3_kernel_stats.csv) and the split-K weight gradient g^T y (gemm_tn_split_kernel<true>); the one that
+    # profiles/r04_cfg3_kernel_stats.csv) and the split-K weight gradient g^T y (gemm_tn_full_kernel<true>); the one that
     # takes longer per launch is reported.  (No library GEMM is left in the step: DESIGN 4.7.)
     g_, x_ = torch.randn(N, W, device=device), torch.randn(N, W, device=device)
     sp = _lib.load().qot_gemm_tn_splits(W, W, N)
@@ -432,7 +432,7 @@ def lightpath_measurement(device, steps):
     if ms_nt >= ms_tn:
         ms_k, kname, tkey = ms_nt, "gemm256_nt_kernel<true, true> (projection x' W^T, BatchNorm+ReLU in the operand load, logits in the epilogue)", "gemm256_nt_kernel<true, true>"
     else:
-        ms_k, kname, tkey = ms_tn, "gemm_tn_split_kernel<true> (weight gradient g^T y of GATConv.lin)", "gemm_tn_split_kernel<true>"
+        ms_k, kname, tkey = ms_tn, "gemm_tn_full_kernel<true> (weight gradient g^T y of GATConv.lin)", "gemm_tn_full_kernel<true>"
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r04_cfg3_traffic.json")
     if os.path.exists(tpath):
@@ -454,7 +454,7 @@ def lightpath_measurement(device, steps):
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflops / ms_k / 1e9 / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "alg_flops_per_launch": kflops, "alg_bytes_per_launch": 8 * N * W + 4 * W * W,
                      "ms_per_launch": ms_k, "other_kernel_ms": {"gemm256_nt_kernel<true, true>": ms_nt,
-                                                                 "gemm_tn_split_kernel<true>": ms_tn},
+                                                                 "gemm_tn_full_kernel<true>": ms_tn},
                      "traffic_source": "profiles/r04_cfg3_traffic.json (per-kernel HBM bytes and GB/s of every cfg3 kernel)"},
     }
 

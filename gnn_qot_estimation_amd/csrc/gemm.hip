@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_split_kernel(const float* __re
     }
 }
 
-// The same product when EVERY stage is full (K a multiple of 32: cfg3's 707 008 rows): the loop body without a branch
-// (the stage after the last one re-reads it; the copy is never multiplied), operands through buffer loads and the
+// The same product with the loop body free of branches (whole stages only; the stage after the last one re-reads it, the
+// copy is never multiplied; a ragged end of K is one masked stage behind the loop), operands through buffer loads and the
 // interleave pinned with sched_group_barrier as in gemm256.hip -- left to the scheduler the fragment reads sat one or two
 // MFMAs in front of their use (`ds_read2; s_waitcnt lgkmcnt(0)` before every group of six).
 template <bool AFFINE>
@@ -510,7 +510,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_full_kernel(const float* __res
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
-    const int64_t nk = (kend - kbeg) / kGemmBK;           // whole stages only (host side)
+    const int64_t nk = (kend - kbeg) / kGemmBK;           // whole stages; a ragged end of K (last split only) follows the loop
+    const int tail = (int)((kend - kbeg) - nk * kGemmBK);
     if (nk > 0) {
         load(kbeg);
         stash(0);
@@ -560,6 +561,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_full_kernel(const float* __res
 #undef QOT_V
 #undef QOT_D
 #undef QOT_W
+    if (tail > 0) {
+        // the last < 32 rows of K (K not a multiple of 32: last split only): one masked stage, not pipelined
+        __syncthreads();
+        const int64_t k0 = kbeg + nk * kGemmBK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool ok = kr + s < tail;
+            const int64_t k = ok ? k0 + kr + s : k0;
+            pa[s] = ld4(A + k * lda + ca);
+            pb[s] = ld4(B + k * ldb + cb);
+            if (AFFINE) pb[s] = affine_relu4<true>(pb[s], sc, sh);
+            if (!ok) { pa[s] = f4zero(); pb[s] = f4zero(); }
+            st4(&lds[0][0][tn_dword(kr + s, 4 * q)], pa[s]);
+            st4(&lds[0][1][tn_dword(kr + s, 4 * q)], pb[s]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            tn_read_frag(f0, lds[0][0], lds[0][1], p, wm, wn, hi, r31);
+            tn_pair_mfma(f0, c);
+        }
+        __syncthreads();
+    }
     float* Cp = Cpart + (int64_t)split * M * N;
     float* tile = &lds[0][0][0];
     gemm_tile_to_lds(tile, c, wm, wn, hi, r31);
@@ -685,7 +709,7 @@ extern "C" int qot_gemm_tn_planes(const float* A, int64_t lda, const float* B, i
     const int64_t grid = (int64_t)((N + kGemmBN - 1) / kGemmBN) * ((M + kGemmBM - 1) / kGemmBM) * splits;
     if (grid > 0x7fffffff) return QOT_ERR_UNSUPPORTED;
     // every stage full and 32-bit byte offsets: the branch-free, pinned form
-    const bool full = (K % kGemmBK) == 0 && (uint64_t)K * (uint64_t)lda * 4 < (1ull << 32) &&
+    const bool full = (uint64_t)K * (uint64_t)lda * 4 < (1ull << 32) &&
                       (uint64_t)K * (uint64_t)ldb * 4 < (1ull << 32) && !getenv("QOT_NO_GEMM_TN_FULL");
     if (full && scale)
         gemm_tn_full_kernel<true><<<(int)grid, 256, 0, (hipStream_t)stream>>>(A, lda, B, ldb, Cpart, M, N, K, kchunk, splits, scale, shift);
