@@ -132,14 +132,20 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         capturable = not self.dp or (dist.is_initialized() and dist.get_backend() == "nccl")
-        if capturable:
+        # with a collective inside, the capture is thread-local: the process group's watchdog thread polls its events while
+        # this thread captures, and in the default (global) mode a call from ANOTHER thread can invalidate a capture; one
+        # retry before falling back (the forced-DP bench test failed once in this round's ~25 suite runs, cause not seen)
+        mode = dict(capture_error_mode="thread_local") if self.dp else {}
+        for attempt in range(2 if (capturable and self.dp) else 1):
+            if not capturable:
+                break
             try:
                 self.graph_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_fb):
+                with torch.cuda.graph(self.graph_fb, **mode):
                     self._eager()
                 if self.spg > 1:             # several whole steps per replay: every step still runs every kernel
                     self.graph_multi = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph_multi, pool=self.graph_fb.pool()):
+                    with torch.cuda.graph(self.graph_multi, pool=self.graph_fb.pool(), **mode):
                         for _ in range(self.spg):
                             self._eager()
                 self.collective_in_graph = self.dp
@@ -150,7 +156,7 @@ class TrainStep:
                 self.capture_error = repr(e)[:400]
                 self.graph_fb = self.graph_multi = None
                 torch.cuda.synchronize()
-        else:
+        if not capturable:
             self.capture_error = f"backend {dist.get_backend() if dist.is_initialized() else None} is not stream-capturable"
         self.collective_in_graph = False
         self.spg = 1

@@ -255,7 +255,9 @@ class StepReplayer:
             return True
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        # (a captured collective: thread-local capture mode -- the process group's watchdog thread polls its events meanwhile)
+        mode = dict(capture_error_mode="thread_local") if self.collective else {}
+        with torch.cuda.graph(g, pool=self.pool, **mode):
             self._step(data, training)
         self.graphs[key] = g
         g.replay()                      # capture records, it does not execute
