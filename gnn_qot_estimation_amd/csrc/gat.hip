@@ -51,58 +51,161 @@ __global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict
 // (r02 kept sums of (out - bias) and its square: for a channel with |mean - bias| >> std -- behind a ReLU, or large
 // activations -- E[d^2] - E[d]^2 lost the variance's leading bits.)
 template <int HEADS, int C>
-__global__ __launch_bounds__(256) void gat_fwd_kernel(
+__global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ bias, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, float* __restrict__ out, float* __restrict__ stats, int64_t N,
     float ns, float* __restrict__ bn_partials) {
     using G = GatCfg<HEADS, C>;
-    __shared__ float4 red1[256];
-    __shared__ float4 red2[256];
+    // r04 walk: every lane group (slot) takes a CONTIGUOUS run of its workgroup's chunk and keeps the source rows of the
+    // destination it just finished in a slot-private LDS image (no barrier: only this lane group reads or writes it).  The
+    // batches' graphs are numbered along their structure -- LightpathGNN's are chains (lightpath_training/dataset.py): the
+    // sources of destination i are i - 1, i, i + 1 -- so of the next destination's rows all but one are already there; that
+    // one is requested a destination ahead (pf), and the index reads two ahead.  Every z row then leaves L2 once (the
+    // interleaved walk of r03 re-read 46 % of z: 2.15 GB for 1.47 at cfg3) and a destination waits for no round trip that
+    // was not started a whole destination earlier.  Any other numbering stays correct: a source that is neither cached nor
+    // prefetched is a plain load, EB of them in flight as before.
+    constexpr int EB = G::NV >= 4 ? 2 : 3;
+    constexpr int HC4 = G::HC / 4;
+    __shared__ float4 cache[G::RPB * EB * HC4];
+    static_assert(sizeof(float4) * G::RPB * EB * HC4 >= 2 * 256 * sizeof(float4) + 256 * sizeof(int), "reduction scratch aliases the cache");
+    __shared__ float lcache[EB * G::NV * 256];          // the cached rows' source logits, [row][v][thread]
+    float4* red1 = cache;
+    float4* red2 = cache + 256;
+    int* rcnt = reinterpret_cast<int*>(cache + 512);
     const int sub = threadIdx.x % G::TPR;
-    const int slot = threadIdx.x / G::TPR;
+    // a full wave per destination (HC >= 256): the slot is wave-uniform -- said so, the walk's index state (row pointers,
+    // sources, cache tags, the decisions made on them) lives in scalar registers and the row addresses are a scalar base +
+    // one lane offset
+    const int slot = G::TPR == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / G::TPR);
+    float4* mine = cache + (size_t)slot * EB * HC4;
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + G::RPB - 1) / G::RPB * G::RPB;
     const int64_t r0 = (int64_t)blk * chunk;
     const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
+    const int64_t run = chunk / G::RPB;
+    const int64_t i0 = r0 + (int64_t)slot * run;
+    const int64_t i1 = (i0 + run < r1) ? i0 + run : r1;
     int hh[G::NV];
-    float4 bz[G::NV], s1[G::NV], s2[G::NV], d0[G::NV];
+    float4 s1[G::NV], s2[G::NV], d0[G::NV];
 #pragma unroll
     for (int v = 0; v < G::NV; ++v) {
         hh[v] = (4 * (sub + G::TPR * v)) / C;
-        bz[v] = ld4(bias + 4 * (sub + G::TPR * v));
         s1[v] = f4zero(); s2[v] = f4zero(); d0[v] = f4zero();
     }
+    // index reads, branch-free: rows past the matrix are clamped to its last row and slots past a destination's in-edges to
+    // its last one (what they fetch is never used)
+    const int elast = rowptr[N] - 1;
+    auto ptrs = [&](int64_t r, int& b, int& e_) {
+        const int64_t rc = r < N ? r : N - 1;
+        b = rowptr[rc];
+        e_ = rowptr[rc + 1];
+    };
+    auto srcs = [&](int b, int e_, int (&j)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int q = (b + e < e_) ? b + e : e_ - 1;
+            q = q < elast ? q : elast;
+            j[e] = elast >= 0 ? col[q > 0 ? q : 0] : 0;
+        }
+    };
+    int beg, end, nbeg, nend, b2, e2;
+    int jc[EB], jn[EB], cid[EB];
+    int pfid = -1;
+    float4 pf[G::NV];
+    float pfa[G::NV], adn[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) {
+        pf[v] = f4zero();
+        pfa[v] = 0.f;
+        adn[v] = a_dst[(i0 < N ? i0 : N - 1) * HEADS + hh[v]];
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) cid[e] = -1;
+    ptrs(i0, beg, end);
+    ptrs(i0 + 1, nbeg, nend);
+    ptrs(i0 + 2, b2, e2);
+    srcs(beg, end, jc);
+    srcs(nbeg, nend, jn);
     int nrows = 0;
-    for (int64_t i = r0 + slot; i < r1; i += G::RPB, ++nrows) {
+    for (int64_t i = i0; i < i1; ++i, ++nrows) {
+        int b3, e3, j2[EB];
+        ptrs(i + 3, b3, e3);
+        srcs(b2, e2, j2);
+        // the row of destination i + 1 that this destination does not bring along: requested now
+        int pid = -1;
+        if (i + 1 < i1) {
+#pragma unroll
+            for (int e = EB - 1; e >= 0; --e) {
+                bool have = nbeg + e >= nend;
+#pragma unroll
+                for (int k = 0; k < EB; ++k) have = have || (beg + k < end && jn[e] == jc[k]);
+                if (!have) pid = jn[e];
+            }
+        }
+        const bool any = beg < end;
         float ad[G::NV], m[G::NV], l[G::NV];
         float4 acc[G::NV];
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
-            ad[v] = a_dst[i * HEADS + hh[v]];
+            ad[v] = adn[v];
+            adn[v] = a_dst[(i + 1 < N ? i + 1 : i) * HEADS + hh[v]];
             m[v] = -INFINITY;
             l[v] = 0.f;
             acc[v] = f4zero();
         }
-        const int beg = rowptr[i], end = rowptr[i + 1];
-        // EB in-edges in flight per lane group: their source ids are requested together, then their rows together.  r04: four
-        // for every width (wide rows had one: a destination of LightpathGNN's chain graphs -- three in-edges with the self loop
-        // -- then cost seven dependent round trips instead of three): 788 -> 743 us per layer at cfg3.  The same batching in
-        // the two backward passes measured WORSE (729 -> 826, 823 -> 844 us: they run at 4-5 TB/s of counter traffic, and the
-        // batch's padding slots re-read rows): they keep one edge at a time.
-        constexpr int EB = 4;
         for (int p = beg; p < end; p += EB) {
-            int64_t jj[EB];
             float4 zz[EB][G::NV];
             float as_[EB][G::NV];
+            const bool first = p == beg;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                jj[e] = col[(p + e < end) ? p + e : p];
+                const int64_t j = jc[e];
+                int where = -1;                              // -1: load, EB: the prefetched row, k: cache row k
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < EB; ++k) where = (jc[e] == cid[k]) ? k : where;
+                    where = (jc[e] == pfid) ? EB : where;
+                }
+                if (where < 0) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
+                        as_[e][v] = a_src[j * HEADS + hh[v]];
+                    }
+                } else if (where == EB) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) { zz[e][v] = pf[v]; as_[e][v] = pfa[v]; }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        zz[e][v] = mine[where * HC4 + sub + G::TPR * v];
+                        as_[e][v] = lcache[(where * G::NV + v) * 256 + threadIdx.x];
+                    }
+                }
+            }
+            if (first && pid >= 0) {             // (pf has been handed to zz: its registers take the next destination's row)
 #pragma unroll
                 for (int v = 0; v < G::NV; ++v) {
-                    zz[e][v] = ld4(z + jj[e] * G::HC + 4 * (sub + G::TPR * v));
-                    as_[e][v] = a_src[jj[e] * HEADS + hh[v]];
+                    pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
+                    pfa[v] = a_src[(int64_t)pid * HEADS + hh[v]];
                 }
+            }
+            if (first) {          // this destination's rows are the next one's cache (slots past its in-edges: empty)
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    cid[e] = (p + e < end) ? jc[e] : -1;
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        mine[e * HC4 + sub + G::TPR * v] = zz[e][v];
+                        lcache[(e * G::NV + v) * 256 + threadIdx.x] = as_[e][v];
+                    }
+                }
+            }
+            const int pnext = p + EB;
+            if (pnext < end) {                 // a destination with more than EB in-edges: the next batch of sources
+#pragma unroll
+                for (int e = 0; e < EB; ++e) jc[e] = col[(pnext + e < end) ? pnext + e : pnext];
             }
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
@@ -120,12 +223,16 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
                 }
             }
         }
+        if (beg >= end) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) cid[e] = -1;
+        }
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
             const int c = 4 * (sub + G::TPR * v);
             const float denom = l[v] + 1e-16f;
             const float4 d = scale4(1.0f / denom, acc[v]);            // out - bias
-            st4(out + i * G::HC + c, add4(d, bz[v]));
+            st4(out + i * G::HC + c, add4(d, ld4(bias + c)));
             if (nrows == 0) d0[v] = d;
             const float4 e = sub4(d, d0[v]);
             s1[v] = add4(s1[v], e);
@@ -135,9 +242,12 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(
                 stats[(i * HEADS + hh[v]) * 2 + 1] = denom;
             }
         }
+        beg = nbeg; end = nend; nbeg = b2; nend = e2; b2 = b3; e2 = e3;
+        pfid = any ? pid : -1;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) { jc[e] = jn[e]; jn[e] = j2[e]; }
     }
     if (bn_partials) {          // fixed order: slots 0..RPB-1 of this workgroup (Chan merges), then the workgroups
-        __shared__ int rcnt[256];
         // this slot's (count, mean, M2) per column from its shifted sums
         const float fn = (float)nrows, rn = nrows > 0 ? 1.0f / fn : 0.f;
 #pragma unroll
