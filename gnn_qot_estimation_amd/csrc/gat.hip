@@ -7,6 +7,7 @@
 //
 // Mapping: TPR = min(64, HC/4) lanes per destination, NV = HC/(4*TPR) float4 per lane;
 // float4 number v of lane `sub` covers channels 4*(sub + TPR*v) .. +3, all in one head.
+#include <cstdint>
 #include "common.hpp"
 #include "mfma_tile.hpp"      // num_cus()
 
@@ -237,10 +238,8 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kern
             const float4 e = sub4(d, d0[v]);
             s1[v] = add4(s1[v], e);
             s2[v] = make_float4(fmaf(e.x, e.x, s2[v].x), fmaf(e.y, e.y, s2[v].y), fmaf(e.z, e.z, s2[v].z), fmaf(e.w, e.w, s2[v].w));
-            if (c % C == 0) {
-                stats[(i * HEADS + hh[v]) * 2] = (beg < end) ? m[v] : 0.f;
-                stats[(i * HEADS + hh[v]) * 2 + 1] = denom;
-            }
+            if (c % C == 0)
+                *reinterpret_cast<float2*>(stats + (i * HEADS + hh[v]) * 2) = make_float2((beg < end) ? m[v] : 0.f, denom);
         }
         beg = nbeg; end = nend; nbeg = b2; nend = e2; b2 = b3; e2 = e3;
         pfid = any ? pid : -1;
@@ -285,63 +284,202 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kern
 
 // destination pass of the backward: per (edge, head) alpha and dalpha = <g_i,h, z_j,h>,
 // delta_{i,h} = sum_e alpha dalpha, grad_a_dst[i,h] = sum_e alpha (dalpha - delta) lrelu'(raw).
+// Same walk as the forward (r04): a contiguous run of destinations per lane group, the previous destination's z rows and
+// source logits in a slot-private LDS image, the one row the next destination adds and its own g row, logit and softmax
+// statistics requested a destination ahead, the index reads two ahead.  (r03: one workgroup per RPB destinations, one
+// in-edge at a time: seven dependent round trips per chain destination, 733 us at cfg3 for 3.0 GB.)
 template <int HEADS, int C>
-__global__ __launch_bounds__(256) void gat_bwd_dst_kernel(
+__global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_kernel(
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, float* __restrict__ gad,
     float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns) {
     using G = GatCfg<HEADS, C>;
+    constexpr int EB = G::NV >= 4 ? 2 : 3;
+    constexpr int HC4 = G::HC / 4;
+    __shared__ float4 cache[G::RPB * EB * HC4];
+    __shared__ float lcache[EB * G::NV * 256];
     const int sub = threadIdx.x % G::TPR;
-    const int64_t i = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
-    if (i >= N) return;
+    const int slot = G::TPR == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / G::TPR);
+    float4* mine = cache + (size_t)slot * EB * HC4;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + G::RPB - 1) / G::RPB * G::RPB;
+    const int64_t r0 = (int64_t)blk * chunk;
+    const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
+    const int64_t run = chunk / G::RPB;
+    const int64_t i0 = r0 + (int64_t)slot * run;
+    const int64_t i1 = (i0 + run < r1) ? i0 + run : r1;
     int hh[G::NV];
-    float ad[G::NV], m[G::NV], inv[G::NV], sada[G::NV], sal[G::NV], salk[G::NV];
-    float4 gi[G::NV];
 #pragma unroll
-    for (int v = 0; v < G::NV; ++v) {
-        const int c = 4 * (sub + G::TPR * v);
-        hh[v] = c / C;
-        ad[v] = a_dst[i * HEADS + hh[v]];
-        m[v] = stats[(i * HEADS + hh[v]) * 2];
-        inv[v] = 1.0f / stats[(i * HEADS + hh[v]) * 2 + 1];
-        gi[v] = ld4(g + i * G::HC + c);
-        sada[v] = sal[v] = salk[v] = 0.f;
-    }
-    const int beg = rowptr[i], end = rowptr[i + 1];
-    for (int p = beg; p < end; ++p) {
-        const int64_t j = col[p];
+    for (int v = 0; v < G::NV; ++v) hh[v] = (4 * (sub + G::TPR * v)) / C;
+    const int elast = rowptr[N] - 1;
+    auto ptrs = [&](int64_t r, int& b_, int& e_) {
+        const int64_t rc = r < N ? r : N - 1;
+        b_ = rowptr[rc];
+        e_ = rowptr[rc + 1];
+    };
+    auto srcs = [&](int b_, int e_, int (&j)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int q = (b_ + e < e_) ? b_ + e : e_ - 1;
+            q = q < elast ? q : elast;
+            j[e] = elast >= 0 ? col[q > 0 ? q : 0] : 0;
+        }
+    };
+    // the destination's own operands, one destination ahead
+    float adn[G::NV], mn_[G::NV], dn_[G::NV];
+    float4 gn[G::NV];
+    auto own = [&](int64_t r) {
+        const int64_t rc = r < N ? r : N - 1;
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            adn[v] = a_dst[rc * HEADS + hh[v]];
+            const float2 st = *reinterpret_cast<const float2*>(stats + (rc * HEADS + hh[v]) * 2);
+            mn_[v] = st.x;
+            dn_[v] = st.y;
+            gn[v] = ld4(g + rc * G::HC + 4 * (sub + G::TPR * v));
+        }
+    };
+    int beg, end, nbeg, nend, b2, e2;
+    int jc[EB], jn[EB], cid[EB];
+    int pfid = -1;
+    float4 pf[G::NV];
+    float pfa[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) { pf[v] = f4zero(); pfa[v] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) cid[e] = -1;
+    ptrs(i0, beg, end);
+    ptrs(i0 + 1, nbeg, nend);
+    ptrs(i0 + 2, b2, e2);
+    srcs(beg, end, jc);
+    srcs(nbeg, nend, jn);
+    own(i0);
+    for (int64_t i = i0; i < i1; ++i) {
+        int b3, e3, j2[EB];
+        ptrs(i + 3, b3, e3);
+        srcs(b2, e2, j2);
+        int pid = -1;
+        if (i + 1 < i1) {
+#pragma unroll
+            for (int e = EB - 1; e >= 0; --e) {
+                bool have = nbeg + e >= nend;
+#pragma unroll
+                for (int k = 0; k < EB; ++k) have = have || (beg + k < end && jn[e] == jc[k]);
+                if (!have) pid = jn[e];
+            }
+        }
+        const bool any = beg < end;
+        float ad[G::NV], m[G::NV], inv[G::NV], sada[G::NV], sal[G::NV], salk[G::NV];
+        float4 gi[G::NV];
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            ad[v] = adn[v];
+            m[v] = mn_[v];
+            inv[v] = 1.0f / dn_[v];
+            gi[v] = gn[v];
+            sada[v] = sal[v] = salk[v] = 0.f;
+        }
+        own(i + 1);
+        for (int p = beg; p < end; p += EB) {
+            float4 zz[EB][G::NV];
+            float as_[EB][G::NV];
+            const bool first = p == beg;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int64_t j = jc[e];
+                int where = -1;                              // -1: load, EB: the prefetched row, k: cache row k
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < EB; ++k) where = (jc[e] == cid[k]) ? k : where;
+                    where = (jc[e] == pfid) ? EB : where;
+                }
+                if (where < 0) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
+                        as_[e][v] = a_src[j * HEADS + hh[v]];
+                    }
+                } else if (where == EB) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) { zz[e][v] = pf[v]; as_[e][v] = pfa[v]; }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        zz[e][v] = mine[where * HC4 + sub + G::TPR * v];
+                        as_[e][v] = lcache[(where * G::NV + v) * 256 + threadIdx.x];
+                    }
+                }
+            }
+            if (first && pid >= 0) {
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
+                    pfa[v] = a_src[(int64_t)pid * HEADS + hh[v]];
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    cid[e] = (p + e < end) ? jc[e] : -1;
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        mine[e * HC4 + sub + G::TPR * v] = zz[e][v];
+                        lcache[(e * G::NV + v) * 256 + threadIdx.x] = as_[e][v];
+                    }
+                }
+            }
+            const int pnext = p + EB;
+            if (pnext < end) {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) jc[e] = col[(pnext + e < end) ? pnext + e : pnext];
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                if (e > 0 && p + e >= end) break;
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    const int c = 4 * (sub + G::TPR * v);
+                    const float da = group_sum<G::LPH>(dot4(gi[v], zz[e][v]));
+                    const float raw = as_[e][v] + ad[v];
+                    const float s_ = raw > 0.f ? raw : ns * raw;
+                    const float lk = raw > 0.f ? 1.0f : ns;
+                    const float a = __expf(s_ - m[v]) * inv[v];
+                    sada[v] = fmaf(a, da, sada[v]);
+                    sal[v] = fmaf(a * lk, da, sal[v]);
+                    salk[v] = fmaf(a, lk, salk[v]);
+                    if (c % C == 0)
+                        *reinterpret_cast<float2*>(escr + ((int64_t)(p + e) * HEADS + hh[v]) * 2) = make_float2(a, da);
+                }
+            }
+        }
+        if (!any) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) cid[e] = -1;
+        }
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
             const int c = 4 * (sub + G::TPR * v);
-            float4 zj = ld4(z + j * G::HC + c);
-            float da = group_sum<G::LPH>(dot4(gi[v], zj));
-            float raw = a_src[j * HEADS + hh[v]] + ad[v];
-            float s = raw > 0.f ? raw : ns * raw;
-            float lk = raw > 0.f ? 1.0f : ns;
-            float a = __expf(s - m[v]) * inv[v];
-            sada[v] = fmaf(a, da, sada[v]);
-            sal[v] = fmaf(a * lk, da, sal[v]);
-            salk[v] = fmaf(a, lk, salk[v]);
             if (c % C == 0) {
-                escr[((int64_t)p * HEADS + hh[v]) * 2] = a;
-                escr[((int64_t)p * HEADS + hh[v]) * 2 + 1] = da;
+                delta[i * HEADS + hh[v]] = sada[v];
+                gad[i * HEADS + hh[v]] = sal[v] - sada[v] * salk[v];
             }
         }
-    }
+        beg = nbeg; end = nend; nbeg = b2; nend = e2; b2 = b3; e2 = e3;
+        pfid = any ? pid : -1;
 #pragma unroll
-    for (int v = 0; v < G::NV; ++v) {
-        const int c = 4 * (sub + G::TPR * v);
-        if (c % C == 0) {
-            delta[i * HEADS + hh[v]] = sada[v];
-            gad[i * HEADS + hh[v]] = sal[v] - sada[v] * salk[v];
-        }
+        for (int e = 0; e < EB; ++e) { jc[e] = jn[e]; jn[e] = j2[e]; }
     }
 }
 
 // source pass over the CSC: grad_z_j = sum_{e: j->i} alpha_e g_i ; grad_a_src[j,h] = sum_e ds_e.
+// The forward's walk (r04) over the transposed index: a contiguous run of sources per lane group, the g rows (and
+// a_dst / delta) of the previous source's destinations in a slot-private LDS image, the one row the next source adds
+// requested a source ahead, the next source's per-edge (alpha, dalpha) pairs requested as soon as this one's are used, the
+// index reads (destinations and CSR positions) two ahead.  (r03: one workgroup per RPB sources, one out-edge at a time:
+// 823 us at cfg3 for 3.0 GB.)
 template <int HEADS, int C>
-__global__ __launch_bounds__(256, 8) void gat_bwd_src_kernel(
+__global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_src_kernel(
     const float* __restrict__ g, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ escr, const float* __restrict__ delta,
     const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
@@ -350,43 +488,183 @@ __global__ __launch_bounds__(256, 8) void gat_bwd_src_kernel(
     // att_src != NULL: the logits were formed from z inside the operator (gat_logits_kernel), so their gradient
     // flows back into grad_z here: + grad_a_src[j,h] att_src[h,:] + grad_a_dst[j,h] att_dst[h,:]
     using G = GatCfg<HEADS, C>;
+    constexpr int EB = G::NV >= 4 ? 2 : 3;
+    constexpr int HC4 = G::HC / 4;
+    __shared__ float4 cache[G::RPB * EB * HC4];
+    __shared__ float2 lcache[EB * G::NV * 256];          // (a_dst, delta) of the cached rows, [row][v][thread]
     const int sub = threadIdx.x % G::TPR;
-    const int64_t j = (int64_t)xcd_block(blockIdx.x, gridDim.x) * G::RPB + threadIdx.x / G::TPR;
-    if (j >= N) return;
+    const int slot = G::TPR == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / G::TPR);
+    float4* mine = cache + (size_t)slot * EB * HC4;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + G::RPB - 1) / G::RPB * G::RPB;
+    const int64_t r0 = (int64_t)blk * chunk;
+    const int64_t r1 = (r0 + chunk < N) ? r0 + chunk : N;
+    const int64_t run = chunk / G::RPB;
+    const int64_t j0 = r0 + (int64_t)slot * run;
+    const int64_t j1 = (j0 + run < r1) ? j0 + run : r1;
     int hh[G::NV];
-    float as[G::NV], sds[G::NV];
-    float4 acc[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) hh[v] = (4 * (sub + G::TPR * v)) / C;
+    const int elast = rowptr_t[N] - 1;
+    auto ptrs = [&](int64_t r, int& b_, int& e_) {
+        const int64_t rc = r < N ? r : N - 1;
+        b_ = rowptr_t[rc];
+        e_ = rowptr_t[rc + 1];
+    };
+    auto dsts = [&](int b_, int e_, int (&ii)[EB], int (&pp)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int q = (b_ + e < e_) ? b_ + e : e_ - 1;
+            q = q < elast ? q : elast;
+            q = q > 0 ? q : 0;
+            ii[e] = elast >= 0 ? col_t[q] : 0;
+            pp[e] = elast >= 0 ? pos_t[q] : 0;
+        }
+    };
+    float asn[G::NV];                                   // the source's own logit, one source ahead
+    float2 ec[EB][G::NV];                               // (alpha, dalpha) of the source's first EB out-edges
+    auto edge_pairs = [&](const int (&pp)[EB]) {
+#pragma unroll
+        for (int e = 0; e < EB; ++e)
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v)
+                ec[e][v] = *reinterpret_cast<const float2*>(escr + ((int64_t)pp[e] * HEADS + hh[v]) * 2);
+    };
+    int beg, end, nbeg, nend, b2, e2;
+    int ic[EB], in_[EB], pc[EB], pn[EB], cid[EB];
+    int pfid = -1;
+    float4 pf[G::NV];
+    float2 pfa[G::NV];
 #pragma unroll
     for (int v = 0; v < G::NV; ++v) {
-        hh[v] = (4 * (sub + G::TPR * v)) / C;
-        as[v] = a_src[j * HEADS + hh[v]];
-        sds[v] = 0.f;
-        acc[v] = f4zero();
+        pf[v] = f4zero();
+        pfa[v] = make_float2(0.f, 0.f);
+        asn[v] = a_src[(j0 < N ? j0 : N - 1) * HEADS + hh[v]];
     }
-    const int beg = rowptr_t[j], end = rowptr_t[j + 1];
-    for (int t = beg; t < end; ++t) {
-        const int64_t i = col_t[t];
-        const int64_t p = pos_t[t];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) cid[e] = -1;
+    ptrs(j0, beg, end);
+    ptrs(j0 + 1, nbeg, nend);
+    ptrs(j0 + 2, b2, e2);
+    dsts(beg, end, ic, pc);
+    dsts(nbeg, nend, in_, pn);
+    edge_pairs(pc);
+    for (int64_t j = j0; j < j1; ++j) {
+        int b3, e3, i2[EB], p2[EB];
+        ptrs(j + 3, b3, e3);
+        dsts(b2, e2, i2, p2);
+        int pid = -1;
+        if (j + 1 < j1) {
+#pragma unroll
+            for (int e = EB - 1; e >= 0; --e) {
+                bool have = nbeg + e >= nend;
+#pragma unroll
+                for (int k = 0; k < EB; ++k) have = have || (beg + k < end && in_[e] == ic[k]);
+                if (!have) pid = in_[e];
+            }
+        }
+        const bool any = beg < end;
+        float as[G::NV], sds[G::NV];
+        float4 acc[G::NV];
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) {
-            const float a = escr[(p * HEADS + hh[v]) * 2];
-            const float da = escr[(p * HEADS + hh[v]) * 2 + 1];
-            const float raw = as[v] + a_dst[i * HEADS + hh[v]];
-            const float lk = raw > 0.f ? 1.0f : ns;
-            sds[v] += a * (da - delta[i * HEADS + hh[v]]) * lk;
-            acc[v] = fma4(a, ld4(g + i * G::HC + 4 * (sub + G::TPR * v)), acc[v]);
+            as[v] = asn[v];
+            asn[v] = a_src[(j + 1 < N ? j + 1 : j) * HEADS + hh[v]];
+            sds[v] = 0.f;
+            acc[v] = f4zero();
         }
-    }
+        for (int t = beg; t < end; t += EB) {
+            float4 gg[EB][G::NV];
+            float2 dd[EB][G::NV];                           // (a_dst, delta) of the edge's destination
+            const bool first = t == beg;
 #pragma unroll
-    for (int v = 0; v < G::NV; ++v) {
-        const int c = 4 * (sub + G::TPR * v);
-        float4 o = acc[v];
-        if (att_src) {
-            o = fma4(sds[v], ld4(att_src + c), o);
-            o = fma4(gad[j * HEADS + hh[v]], ld4(att_dst + c), o);
+            for (int e = 0; e < EB; ++e) {
+                const int64_t i = ic[e];
+                int where = -1;
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < EB; ++k) where = (ic[e] == cid[k]) ? k : where;
+                    where = (ic[e] == pfid) ? EB : where;
+                }
+                if (where < 0) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        gg[e][v] = ld4(g + i * G::HC + 4 * (sub + G::TPR * v));
+                        dd[e][v] = make_float2(a_dst[i * HEADS + hh[v]], delta[i * HEADS + hh[v]]);
+                    }
+                } else if (where == EB) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) { gg[e][v] = pf[v]; dd[e][v] = pfa[v]; }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        gg[e][v] = mine[where * HC4 + sub + G::TPR * v];
+                        dd[e][v] = lcache[(where * G::NV + v) * 256 + threadIdx.x];
+                    }
+                }
+            }
+            if (!first) edge_pairs(pc);                    // (later batches of a wide source: read when needed)
+            if (first && pid >= 0) {
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    pf[v] = ld4(g + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
+                    pfa[v] = make_float2(a_dst[(int64_t)pid * HEADS + hh[v]], delta[(int64_t)pid * HEADS + hh[v]]);
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    cid[e] = (t + e < end) ? ic[e] : -1;
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        mine[e * HC4 + sub + G::TPR * v] = gg[e][v];
+                        lcache[(e * G::NV + v) * 256 + threadIdx.x] = dd[e][v];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                if (e > 0 && t + e >= end) break;
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    const float a = ec[e][v].x;
+                    const float da = ec[e][v].y;
+                    const float raw = as[v] + dd[e][v].x;
+                    const float lk = raw > 0.f ? 1.0f : ns;
+                    sds[v] += a * (da - dd[e][v].y) * lk;
+                    acc[v] = fma4(a, gg[e][v], acc[v]);
+                }
+            }
+            const int tnext = t + EB;
+            if (tnext < end) {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) {
+                    const int q = (tnext + e < end) ? tnext + e : tnext;
+                    ic[e] = col_t[q];
+                    pc[e] = pos_t[q];
+                }
+            }
         }
-        st4(gz + j * G::HC + c, o);
-        if (c % C == 0) gas[j * HEADS + hh[v]] = sds[v];
+        if (!any) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) cid[e] = -1;
+        }
+        if (j + 1 < j1) edge_pairs(pn);                    // the next source's pairs: this one's have been used
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            const int c = 4 * (sub + G::TPR * v);
+            float4 o = acc[v];
+            if (att_src) {
+                o = fma4(sds[v], ld4(att_src + c), o);
+                o = fma4(gad[j * HEADS + hh[v]], ld4(att_dst + c), o);
+            }
+            st4(gz + j * G::HC + c, o);
+            if (c % C == 0) gas[j * HEADS + hh[v]] = sds[v];
+        }
+        beg = nbeg; end = nend; nbeg = b2; nend = e2; b2 = b3; e2 = e3;
+        pfid = any ? pid : -1;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) { ic[e] = in_[e]; in_[e] = i2[e]; pc[e] = pn[e]; pn[e] = p2[e]; }
     }
 }
 
@@ -481,6 +759,17 @@ static int gat_blocks_for(int64_t N) {
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
+// workgroups of a backward walk: one resident round of its kernel (occupancy x CUs), no more than there are row groups
+template <int C>
+static int gat_walk_blocks(const void* kernel, int64_t N) {
+    using G = GatCfg<4, C>;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 2;
+    int64_t b = (N + G::RPB - 1) / G::RPB;
+    const int64_t cap = (int64_t)(occ > 8 ? 8 : occ) * num_cus();
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
 extern "C" size_t qot_gat_bn_partials_floats(int64_t N, int heads, int C) {
     return (size_t)2048 * 2 * (size_t)(heads * C);
 }
@@ -519,6 +808,8 @@ extern "C" int qot_gat_fwd(const float* z, const float* a_src, const float* a_ds
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
     if (N == 0) return QOT_OK;
     if (!z || !a_src || !a_dst || !bias || !col || !out || !stats) return QOT_ERR_BADARG;
+    if ((reinterpret_cast<uintptr_t>(stats) & 7) || ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
         const int nblk = gat_blocks_for<kC>(N);
@@ -537,9 +828,13 @@ extern "C" int qot_gat_bwd_dst(const float* grad_out, const float* z, const floa
     if (N == 0) return QOT_OK;
     if (!grad_out || !z || !a_src || !a_dst || !stats || !col || !grad_a_dst || !escr || !delta)
         return QOT_ERR_BADARG;
+    if (((reinterpret_cast<uintptr_t>(stats) | reinterpret_cast<uintptr_t>(escr)) & 7) ||
+        ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(grad_out)) & 15))
+        return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        gat_bwd_dst_kernel<4, kC><<<grid_for(N, G::RPB), 256, 0, (hipStream_t)stream>>>(
+        gat_bwd_dst_kernel<4, kC><<<gat_walk_blocks<kC>(reinterpret_cast<const void*>(gat_bwd_dst_kernel<4, kC>), N), 256, 0,
+                                    (hipStream_t)stream>>>(
             grad_out, z, a_src, a_dst, stats, rowptr, col, grad_a_dst, escr, delta, N, neg_slope);
     });
     QOT_LAUNCH_CHECK();
@@ -557,9 +852,12 @@ extern "C" int qot_gat_bwd_src(const float* grad_out, const float* a_src, const 
     if (!grad_out || !a_src || !a_dst || !escr || !delta || !col_t || !pos_t || !grad_z || !grad_a_src)
         return QOT_ERR_BADARG;
     if (att_src && (!att_dst || !grad_a_dst)) return QOT_ERR_BADARG;
+    if ((reinterpret_cast<uintptr_t>(escr) & 7) || ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_z)) & 15))
+        return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        gat_bwd_src_kernel<4, kC><<<grid_for(N, G::RPB), 256, 0, (hipStream_t)stream>>>(
+        gat_bwd_src_kernel<4, kC><<<gat_walk_blocks<kC>(reinterpret_cast<const void*>(gat_bwd_src_kernel<4, kC>), N), 256, 0,
+                                    (hipStream_t)stream>>>(
             grad_out, a_src, a_dst, escr, delta, rowptr_t, col_t, pos_t, grad_z, grad_a_src, N,
             neg_slope, att_src, att_dst, grad_a_dst);
     });

@@ -364,7 +364,8 @@ int qot_pool_bwd(const float* grad_out, const int32_t* ptr, const int32_t* batch
 
 /* ---- GATConv (concat heads) ---------------------------------------------------------
  * z[N, heads*C], a_src/a_dst[N, heads]; graph = CSR built with gat_self_loops.
- * out[N, heads*C] (+bias fused); stats[N, heads, 2].
+ * out[N, heads*C] (+bias fused); stats[N, heads, 2].  stats and escr are read and written as (float, float) pairs:
+ * 8-byte aligned, as are all row matrices 16-byte (QOT_ERR_BADARG otherwise).
  * qot_gat_logits: a_src[n,h] = <z[n,h,:], att_src[h,:]>, a_dst likewise (App. B.3), one pass over z.
  * qot_gat_fwd, bn_partials != NULL: also writes per-workgroup column (mean, sum of squared deviations) of out - bias,
  *   [qot_gat_blocks(N, heads, C)][2][heads*C] floats (buffer of qot_gat_bn_partials_floats), which
