@@ -26,7 +26,7 @@ _u64 = C.c_uint64
 _sz = C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/qot_gnn.h declares
-ABI_VERSION = 9          # include/qot_gnn.h: QOT_ABI_VERSION
+ABI_VERSION = 10         # include/qot_gnn.h: QOT_ABI_VERSION
 
 SIGNATURES = {
     "qot_abi_version": (_int, []),
@@ -101,7 +101,7 @@ SIGNATURES = {
     "qot_gat_att_grad": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_gat_chunk_rows": (_i64, [_i64, _int, _int]),
     "qot_bn_stats_from_partials": (_int, [_p, _p, _int, _i64, _i64, _int, _f, _f, _p, _p, _p, _p, _p]),
-    "qot_gat_bwd_dst": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p]),
+    "qot_gat_bwd_dst": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p, _p]),
     "qot_gat_bwd_src": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p, _p, _p]),
     "qot_bn_partials_floats": (_sz, [_i64, _int]),
     "qot_bn_stats": (_int, [_p, _i64, _int, _f, _f, _p, _p, _p, _p, _p, _p]),

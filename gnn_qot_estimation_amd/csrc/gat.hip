@@ -293,12 +293,19 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, float* __restrict__ gad,
-    float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns) {
+    float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns, float* __restrict__ bias_partials) {
+    // bias_partials != NULL: the column sums of g (GATConv's bias gradient) of this workgroup's rows land in
+    // bias_partials[blk][HC] -- every g row passes through here once anyway (r03: a pass of its own over [N, 4C], 178 us
+    // per layer at cfg3); gat_bias_final_kernel adds the workgroups' rows in a fixed order.
     using G = GatCfg<HEADS, C>;
     constexpr int EB = G::NV >= 4 ? 2 : 3;
     constexpr int HC4 = G::HC / 4;
     __shared__ float4 cache[G::RPB * EB * HC4];
     __shared__ float lcache[EB * G::NV * 256];
+    static_assert(sizeof(float4) * G::RPB * EB * HC4 >= 256 * sizeof(float4), "reduction scratch aliases the cache");
+    float4 bsum[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) bsum[v] = f4zero();
     const int sub = threadIdx.x % G::TPR;
     const int slot = G::TPR == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / G::TPR);
     float4* mine = cache + (size_t)slot * EB * HC4;
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_
             m[v] = mn_[v];
             inv[v] = 1.0f / dn_[v];
             gi[v] = gn[v];
+            bsum[v] = add4(bsum[v], gi[v]);
             sada[v] = sal[v] = salk[v] = 0.f;
         }
         own(i + 1);
@@ -469,6 +477,19 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_
         pfid = any ? pid : -1;
 #pragma unroll
         for (int e = 0; e < EB; ++e) { jc[e] = jn[e]; jn[e] = j2[e]; }
+    }
+    if (bias_partials) {                       // slots 0..RPB-1 in order
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) {
+            __syncthreads();
+            cache[threadIdx.x] = bsum[v];
+            __syncthreads();
+            if (threadIdx.x < G::TPR) {
+                float4 a = cache[sub];
+                for (int k = 1; k < G::RPB; ++k) a = add4(a, cache[k * G::TPR + sub]);
+                st4(bias_partials + (int64_t)blk * G::HC + 4 * (sub + G::TPR * v), a);
+            }
+        }
     }
 }
 
@@ -710,6 +731,17 @@ __global__ __launch_bounds__(256) void gat_att_grad_kernel(const float* __restri
     }
 }
 
+__global__ void gat_bias_final_kernel(const float* __restrict__ partials, int nblk, int HC, float* __restrict__ gbias) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per column
+    if (c >= HC) return;
+    const int lane = threadIdx.x & 63;
+    double a = 0.0;
+    for (int k = lane; k < nblk; k += 64) a += (double)partials[(int64_t)k * HC + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) gbias[c] = (float)a;
+}
+
 __global__ void gat_att_grad_final_kernel(const float* __restrict__ partials, int nblk, int HC, float* __restrict__ gsrc,
                                           float* __restrict__ gdst) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per column
@@ -823,9 +855,14 @@ extern "C" int qot_gat_fwd(const float* z, const float* a_src, const float* a_ds
 extern "C" int qot_gat_bwd_dst(const float* grad_out, const float* z, const float* a_src,
                                const float* a_dst, const float* stats, const int32_t* rowptr,
                                const int32_t* col, float* grad_a_dst, float* escr, float* delta,
-                               int64_t N, int heads, int C, float neg_slope, qot_stream_t stream) {
+                               int64_t N, int heads, int C, float neg_slope, float* grad_bias, float* workspace,
+                               qot_stream_t stream) {
     if (N < 0 || !rowptr) return QOT_ERR_BADARG;
-    if (N == 0) return QOT_OK;
+    if (grad_bias && !workspace) return QOT_ERR_BADARG;
+    if (N == 0) {
+        if (grad_bias && heads > 0 && C > 0) QOT_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * heads * C, (hipStream_t)stream));
+        return QOT_OK;
+    }
     if (!grad_out || !z || !a_src || !a_dst || !stats || !col || !grad_a_dst || !escr || !delta)
         return QOT_ERR_BADARG;
     if (((reinterpret_cast<uintptr_t>(stats) | reinterpret_cast<uintptr_t>(escr)) & 7) ||
@@ -833,9 +870,14 @@ extern "C" int qot_gat_bwd_dst(const float* grad_out, const float* z, const floa
         return QOT_ERR_BADARG;
     QOT_DISPATCH_GAT(heads, C, {
         using G = GatCfg<4, kC>;
-        gat_bwd_dst_kernel<4, kC><<<gat_walk_blocks<kC>(reinterpret_cast<const void*>(gat_bwd_dst_kernel<4, kC>), N), 256, 0,
-                                    (hipStream_t)stream>>>(
-            grad_out, z, a_src, a_dst, stats, rowptr, col, grad_a_dst, escr, delta, N, neg_slope);
+        const int nblk = gat_walk_blocks<kC>(reinterpret_cast<const void*>(gat_bwd_dst_kernel<4, kC>), N);
+        gat_bwd_dst_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(
+            grad_out, z, a_src, a_dst, stats, rowptr, col, grad_a_dst, escr, delta, N, neg_slope,
+            grad_bias ? workspace : nullptr);
+        if (grad_bias) {
+            QOT_LAUNCH_CHECK();
+            gat_bias_final_kernel<<<grid_for(G::HC, 4), 256, 0, (hipStream_t)stream>>>(workspace, nblk, G::HC, grad_bias);
+        }
     });
     QOT_LAUNCH_CHECK();
     return QOT_OK;

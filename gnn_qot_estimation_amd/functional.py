@@ -1208,15 +1208,17 @@ class GatFn(torch.autograd.Function):
         gz = torch.empty(N, HC, dtype=torch.float32, device=dev)
         escr = torch.empty(max(graph.cap, 1), heads, 2, dtype=torch.float32, device=dev)
         delta = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        # (the bias gradient -- column sums of g -- rides along: every g row passes through the destination pass once)
+        g_bias = torch.empty(HC, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
         _lib.call("qot_gat_bwd_dst", P(g), P(z), P(a_src), P(a_dst), P(stats), P(graph.rowptr), P(graph.col),
-                  P(gad), P(escr), P(delta), N, heads, C, ns)
+                  P(gad), P(escr), P(delta), N, heads, C, ns, P(g_bias), P(ws))
         # the source pass also sends the logit gradients back into grad_z through the attention vectors
         _lib.call("qot_gat_bwd_src", P(g), P(a_src), P(a_dst), P(escr), P(delta), P(graph.rowptr_t),
                   P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns, P(att_s), P(att_d), P(gad))
         g_att = torch.empty(2, HC, dtype=torch.float32, device=dev)
-        ws = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
         _lib.call("qot_gat_att_grad", P(z), P(gas), P(gad), _off(g_att, 0), _off(g_att, HC), P(ws), N, heads, C)
-        return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), colsum(g), None, None, None, None, None
+        return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), g_bias, None, None, None, None, None
 
 
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)

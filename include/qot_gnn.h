@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* qot_stream_t; /* hipStream_t */
 
-#define QOT_ABI_VERSION 9
+#define QOT_ABI_VERSION 10
 #define QOT_OK 0
 #define QOT_ERR_UNSUPPORTED (-1) /* width / edge_dim not instantiated */
 #define QOT_ERR_BADARG (-2)      /* null pointer, negative size, workspace too small */
@@ -378,11 +378,13 @@ int qot_gat_logits(const float* z, const float* att_src, const float* att_dst, f
 int qot_gat_fwd(const float* z, const float* a_src, const float* a_dst, const float* bias,
                 const int32_t* rowptr, const int32_t* col, float* out, float* stats, int64_t N,
                 int heads, int C, float neg_slope, float* bn_partials, qot_stream_t stream);
-/* destination pass: grad_a_dst[N,heads], escr[cap, heads, 2] = (alpha, dalpha), delta[N,heads] */
+/* destination pass: grad_a_dst[N,heads], escr[cap, heads, 2] = (alpha, dalpha), delta[N,heads].
+ * grad_bias != NULL: also GATConv's bias gradient [heads*C] = column sums of grad_out (every row passes through this
+ * kernel once anyway); workspace: qot_gat_bn_partials_floats(N, heads, C) floats. */
 int qot_gat_bwd_dst(const float* grad_out, const float* z, const float* a_src, const float* a_dst,
                     const float* stats, const int32_t* rowptr, const int32_t* col, float* grad_a_dst,
                     float* escr, float* delta, int64_t N, int heads, int C, float neg_slope,
-                    qot_stream_t stream);
+                    float* grad_bias, float* workspace, qot_stream_t stream);
 /* source pass: grad_z[N, heads*C], grad_a_src[N, heads].  att_src != NULL (logits formed by qot_gat_logits):
  * grad_z also receives grad_a_src[j,h] att_src[h,:] + grad_a_dst[j,h] att_dst[h,:]. */
 int qot_gat_bwd_src(const float* grad_out, const float* a_src, const float* a_dst, const float* escr,
