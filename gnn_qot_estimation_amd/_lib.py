@@ -101,6 +101,9 @@ SIGNATURES = {
     "qot_gat_att_grad": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _int, _p]),
     "qot_gat_chunk_rows": (_i64, [_i64, _int, _int]),
     "qot_bn_stats_from_partials": (_int, [_p, _p, _int, _i64, _i64, _int, _f, _f, _p, _p, _p, _p, _p]),
+    "qot_gat_thin_supported": (_int, [_int, _int, _int]),
+    "qot_gat_fwd_thin": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p]),
+    "qot_gat_bwd_dst_thin": (_int, [_p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p, _p]),
     "qot_gat_bwd_dst": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p, _p]),
     "qot_gat_bwd_src": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _int, _f, _p, _p, _p, _p]),
     "qot_bn_partials_floats": (_sz, [_i64, _int]),

@@ -43,6 +43,30 @@ __global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict
     }
 }
 
+// THIN instantiations (r04): the projected rows z_j = W x_j of a layer with a handful of input features (LightpathGNN's first:
+// K = 5) are FORMED where the dense kernels read them -- K scalars of x_j instead of a 4C-float row, 4 K FMAs per float4 with W
+// (transposed, [K][4C]) in LDS -- so that z is never written or read (1.47 GB each way per pass at cfg3).  Same walk, same cache.
+#define QOT_GAT_THIN_ROWS                                                                                             \
+    extern __shared__ float4 thin_w[];                           /* [K][HC / 4], THIN only */                         \
+    float pfx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     /* the prefetched node's features */                 \
+    if constexpr (THIN) {                                                                                             \
+        for (int e_ = threadIdx.x; e_ < K * G::HC; e_ += 256)                                                         \
+            reinterpret_cast<float*>(thin_w)[e_] = wlin[(int64_t)(e_ % G::HC) * K + e_ / G::HC];                      \
+        __syncthreads();                                                                                              \
+    }                                                                                                                 \
+    auto thin_read = [&](int64_t j_, float(&xk_)[8]) {                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) xk_[k_] = k_ < K ? xin[j_ * K + k_] : 0.f;                   \
+    };                                                                                                                \
+    auto thin_form = [&](const float(&xk_)[8], float4(&r_)[G::NV]) {                                                  \
+        const int sub_ = threadIdx.x % G::TPR;                                                                        \
+        _Pragma("unroll") for (int v_ = 0; v_ < G::NV; ++v_) r_[v_] = f4zero();                                       \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_)                                                              \
+            if (k_ < K) {                                                                                             \
+                _Pragma("unroll") for (int v_ = 0; v_ < G::NV; ++v_)                                                  \
+                    r_[v_] = fma4(xk_[k_], thin_w[k_ * (G::HC / 4) + sub_ + G::TPR * v_], r_[v_]);                    \
+            }                                                                                                         \
+    };
+
 // Forward.  Every workgroup walks a contiguous chunk of destinations (slot s takes rows r0+s, r0+s+RPB, ...), two
 // in-edges in flight per lane group.  bn_partials != NULL: per-workgroup column (mean, M2 = sum of squared deviations) of
 // out - bias land in partials[blk][2][HC] -- the BatchNorm that follows (lightpath_training/models.py:31) gets its batch
@@ -51,13 +75,15 @@ __global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict
 // bias), lanes and workgroups are merged with Chan's pairwise formula in a fixed order (qot_bn_stats_from_partials).
 // (r02 kept sums of (out - bias) and its square: for a channel with |mean - bias| >> std -- behind a ReLU, or large
 // activations -- E[d^2] - E[d]^2 lost the variance's leading bits.)
-template <int HEADS, int C>
+template <int HEADS, int C, bool THIN = false>
 __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ bias, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, float* __restrict__ out, float* __restrict__ stats, int64_t N,
-    float ns, float* __restrict__ bn_partials) {
+    float ns, float* __restrict__ bn_partials, const float* __restrict__ xin = nullptr,
+    const float* __restrict__ wlin = nullptr, int K = 0) {
     using G = GatCfg<HEADS, C>;
+    QOT_GAT_THIN_ROWS
     // r04 walk: every lane group (slot) takes a CONTIGUOUS run of its workgroup's chunk and keeps the source rows of the
     // destination it just finished in a slot-private LDS image (no barrier: only this lane group reads or writes it).  The
     // batches' graphs are numbered along their structure -- LightpathGNN's are chains (lightpath_training/dataset.py): the
@@ -169,14 +195,23 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kern
                     where = (jc[e] == pfid) ? EB : where;
                 }
                 if (where < 0) {
+                    if constexpr (THIN) {
+                        float xk[8];
+                        thin_read(j, xk);
+                        thin_form(xk, zz[e]);
+                    }
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) {
-                        zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
+                        if constexpr (!THIN) zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
                         as_[e][v] = a_src[j * HEADS + hh[v]];
                     }
                 } else if (where == EB) {
+                    if constexpr (THIN) thin_form(pfx, zz[e]);
 #pragma unroll
-                    for (int v = 0; v < G::NV; ++v) { zz[e][v] = pf[v]; as_[e][v] = pfa[v]; }
+                    for (int v = 0; v < G::NV; ++v) {
+                        if constexpr (!THIN) zz[e][v] = pf[v];
+                        as_[e][v] = pfa[v];
+                    }
                 } else {
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) {
@@ -188,9 +223,10 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kern
             if (first && pid >= 0) {             // (pf has been handed to zz: its registers take the next destination's row)
 #pragma unroll
                 for (int v = 0; v < G::NV; ++v) {
-                    pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
+                    if constexpr (!THIN) pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
                     pfa[v] = a_src[(int64_t)pid * HEADS + hh[v]];
                 }
+                if constexpr (THIN) thin_read(pid, pfx);
             }
             if (first) {          // this destination's rows are the next one's cache (slots past its in-edges: empty)
 #pragma unroll
@@ -288,16 +324,18 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_fwd_kern
 // source logits in a slot-private LDS image, the one row the next destination adds and its own g row, logit and softmax
 // statistics requested a destination ahead, the index reads two ahead.  (r03: one workgroup per RPB destinations, one
 // in-edge at a time: seven dependent round trips per chain destination, 733 us at cfg3 for 3.0 GB.)
-template <int HEADS, int C>
+template <int HEADS, int C, bool THIN = false>
 __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_kernel(
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ a_src,
     const float* __restrict__ a_dst, const float* __restrict__ stats,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, float* __restrict__ gad,
-    float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns, float* __restrict__ bias_partials) {
+    float* __restrict__ escr, float* __restrict__ delta, int64_t N, float ns, float* __restrict__ bias_partials,
+    const float* __restrict__ xin = nullptr, const float* __restrict__ wlin = nullptr, int K = 0) {
     // bias_partials != NULL: the column sums of g (GATConv's bias gradient) of this workgroup's rows land in
     // bias_partials[blk][HC] -- every g row passes through here once anyway (r03: a pass of its own over [N, 4C], 178 us
     // per layer at cfg3); gat_bias_final_kernel adds the workgroups' rows in a fixed order.
     using G = GatCfg<HEADS, C>;
+    QOT_GAT_THIN_ROWS
     constexpr int EB = G::NV >= 4 ? 2 : 3;
     constexpr int HC4 = G::HC / 4;
     __shared__ float4 cache[G::RPB * EB * HC4];
@@ -403,14 +441,23 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_
                     where = (jc[e] == pfid) ? EB : where;
                 }
                 if (where < 0) {
+                    if constexpr (THIN) {
+                        float xk[8];
+                        thin_read(j, xk);
+                        thin_form(xk, zz[e]);
+                    }
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) {
-                        zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
+                        if constexpr (!THIN) zz[e][v] = ld4(z + j * G::HC + 4 * (sub + G::TPR * v));
                         as_[e][v] = a_src[j * HEADS + hh[v]];
                     }
                 } else if (where == EB) {
+                    if constexpr (THIN) thin_form(pfx, zz[e]);
 #pragma unroll
-                    for (int v = 0; v < G::NV; ++v) { zz[e][v] = pf[v]; as_[e][v] = pfa[v]; }
+                    for (int v = 0; v < G::NV; ++v) {
+                        if constexpr (!THIN) zz[e][v] = pf[v];
+                        as_[e][v] = pfa[v];
+                    }
                 } else {
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) {
@@ -422,9 +469,10 @@ __global__ __launch_bounds__(256, (HEADS * C >= 1024) ? 2 : 4) void gat_bwd_dst_
             if (first && pid >= 0) {
 #pragma unroll
                 for (int v = 0; v < G::NV; ++v) {
-                    pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
+                    if constexpr (!THIN) pf[v] = ld4(z + (int64_t)pid * G::HC + 4 * (sub + G::TPR * v));
                     pfa[v] = a_src[(int64_t)pid * HEADS + hh[v]];
                 }
+                if constexpr (THIN) thin_read(pid, pfx);
             }
             if (first) {
 #pragma unroll
@@ -793,10 +841,10 @@ static int gat_blocks_for(int64_t N) {
 
 // workgroups of a backward walk: one resident round of its kernel (occupancy x CUs), no more than there are row groups
 template <int C>
-static int gat_walk_blocks(const void* kernel, int64_t N) {
+static int gat_walk_blocks(const void* kernel, int64_t N, size_t dyn_lds = 0) {
     using G = GatCfg<4, C>;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, dyn_lds) != hipSuccess || occ <= 0) occ = 2;
     int64_t b = (N + G::RPB - 1) / G::RPB;
     const int64_t cap = (int64_t)(occ > 8 ? 8 : occ) * num_cus();
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -852,6 +900,42 @@ extern "C" int qot_gat_fwd(const float* z, const float* a_src, const float* a_ds
     return QOT_OK;
 }
 
+// The thin forms: z = x W^T (x [N, K], K <= 8 input features; W [heads*C, K] = GATConv.lin.weight) is formed inside the
+// kernels instead of being read; same outputs, same partials layout (qot_gat_blocks workgroups) as the dense forms.
+// QOT_ERR_UNSUPPORTED when K is not in 1..8 or W^T does not fit next to the walk's LDS image (64 KB per workgroup).
+static bool gat_thin_fits(int heads, int C, int K, size_t* dyn) {
+    if (K < 1 || K > 8 || heads != 4) return false;
+    const size_t HC = (size_t)heads * C;
+    const int EB = HC >= 1024 ? 2 : 3;
+    const size_t rpb = 256 / (HC / 4 < 64 ? HC / 4 : 64);
+    const size_t fixed = rpb * EB * HC * 4 + (size_t)EB * (HC >= 1024 ? 4 : (HC >= 512 ? 2 : 1)) * 256 * 4;
+    *dyn = (size_t)K * HC * 4;
+    return fixed + *dyn <= 64 * 1024;
+}
+
+extern "C" int qot_gat_thin_supported(int heads, int C, int K) {
+    size_t dyn = 0;
+    return gat_thin_fits(heads, C, K, &dyn) ? 1 : 0;
+}
+
+extern "C" int qot_gat_fwd_thin(const float* x, int K, const float* w, const float* a_src, const float* a_dst,
+                                const float* bias, const int32_t* rowptr, const int32_t* col, float* out, float* stats,
+                                int64_t N, int heads, int C, float neg_slope, float* bn_partials, qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    size_t dyn = 0;
+    if (!gat_thin_fits(heads, C, K, &dyn)) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) return QOT_OK;
+    if (!x || !w || !a_src || !a_dst || !bias || !col || !out || !stats) return QOT_ERR_BADARG;
+    if ((reinterpret_cast<uintptr_t>(stats) & 7) || (reinterpret_cast<uintptr_t>(out) & 15)) return QOT_ERR_BADARG;
+    QOT_DISPATCH_GAT(heads, C, {
+        const int nblk = gat_blocks_for<kC>(N);
+        gat_fwd_kernel<4, kC, true><<<nblk, 256, dyn, (hipStream_t)stream>>>(
+            nullptr, a_src, a_dst, bias, rowptr, col, out, stats, N, neg_slope, bn_partials, x, w, K);
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
 extern "C" int qot_gat_bwd_dst(const float* grad_out, const float* z, const float* a_src,
                                const float* a_dst, const float* stats, const int32_t* rowptr,
                                const int32_t* col, float* grad_a_dst, float* escr, float* delta,
@@ -874,6 +958,37 @@ extern "C" int qot_gat_bwd_dst(const float* grad_out, const float* z, const floa
         gat_bwd_dst_kernel<4, kC><<<nblk, 256, 0, (hipStream_t)stream>>>(
             grad_out, z, a_src, a_dst, stats, rowptr, col, grad_a_dst, escr, delta, N, neg_slope,
             grad_bias ? workspace : nullptr);
+        if (grad_bias) {
+            QOT_LAUNCH_CHECK();
+            gat_bias_final_kernel<<<grid_for(G::HC, 4), 256, 0, (hipStream_t)stream>>>(workspace, nblk, G::HC, grad_bias);
+        }
+    });
+    QOT_LAUNCH_CHECK();
+    return QOT_OK;
+}
+
+extern "C" int qot_gat_bwd_dst_thin(const float* grad_out, const float* x, int K, const float* w, const float* a_src,
+                                    const float* a_dst, const float* stats, const int32_t* rowptr, const int32_t* col,
+                                    float* grad_a_dst, float* escr, float* delta, int64_t N, int heads, int C,
+                                    float neg_slope, float* grad_bias, float* workspace, qot_stream_t stream) {
+    if (N < 0 || !rowptr) return QOT_ERR_BADARG;
+    if (grad_bias && !workspace) return QOT_ERR_BADARG;
+    size_t dyn = 0;
+    if (!gat_thin_fits(heads, C, K, &dyn)) return QOT_ERR_UNSUPPORTED;
+    if (N == 0) {
+        if (grad_bias && heads > 0 && C > 0) QOT_HIP(hipMemsetAsync(grad_bias, 0, sizeof(float) * heads * C, (hipStream_t)stream));
+        return QOT_OK;
+    }
+    if (!grad_out || !x || !w || !a_src || !a_dst || !stats || !col || !grad_a_dst || !escr || !delta) return QOT_ERR_BADARG;
+    if (((reinterpret_cast<uintptr_t>(stats) | reinterpret_cast<uintptr_t>(escr)) & 7) ||
+        (reinterpret_cast<uintptr_t>(grad_out) & 15))
+        return QOT_ERR_BADARG;
+    QOT_DISPATCH_GAT(heads, C, {
+        using G = GatCfg<4, kC>;
+        const int nblk = gat_walk_blocks<kC>(reinterpret_cast<const void*>(gat_bwd_dst_kernel<4, kC, true>), N, dyn);
+        gat_bwd_dst_kernel<4, kC, true><<<nblk, 256, dyn, (hipStream_t)stream>>>(
+            grad_out, nullptr, a_src, a_dst, stats, rowptr, col, grad_a_dst, escr, delta, N, neg_slope,
+            grad_bias ? workspace : nullptr, x, w, K);
         if (grad_bias) {
             QOT_LAUNCH_CHECK();
             gat_bias_final_kernel<<<grid_for(G::HC, 4), 256, 0, (hipStream_t)stream>>>(workspace, nblk, G::HC, grad_bias);

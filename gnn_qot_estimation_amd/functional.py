@@ -1221,6 +1221,98 @@ class GatFn(torch.autograd.Function):
         return gz, g_att[0].view(ctx.att_shape), g_att[1].view(ctx.att_shape), g_bias, None, None, None, None, None
 
 
+def gat_thin_ok(x: torch.Tensor, heads: int, C: int) -> bool:
+    """GATConv with a handful of input features (LightpathGNN's first layer: 5) on the thin kernels -- the projection formed
+    inside the attention kernels, ``z`` never materialised (``GatThinFn``).  Large batches only: the handful of tiny launches
+    the logits and the attention-vector gradients take costs more than it saves when the step is launch-bound
+    (``QOT_GAT_THIN_MIN_ROWS``, default 32768); ``QOT_NO_GAT_THIN=1`` switches it off."""
+    if os.environ.get("QOT_NO_GAT_THIN", "0") == "1" or not x.is_cuda or x.dtype != torch.float32 or x.requires_grad:
+        return False
+    if x.dim() != 2 or x.shape[0] < int(os.environ.get("QOT_GAT_THIN_MIN_ROWS", "32768")) or not skinny_ok(x.shape[1], 4):
+        return False
+    return bool(_lib.load().qot_gat_thin_supported(heads, C, x.shape[1]))
+
+
+def _skinny_dw(g, x):
+    """``g^T x`` for ``x [N, F <= 8]`` (fixed-order per-workgroup partials + row sum), ``[C, F]``."""
+    N, C = g.shape
+    F = x.shape[1]
+    nblk = _lib.load().qot_skinny_linear_dw_blocks(N)
+    part = torch.empty(nblk, C * F, dtype=torch.float32, device=g.device)
+    _lib.call("qot_skinny_linear_dw", P(g), P(x), P(part), N, F, C)
+    gw = torch.empty(C * F, dtype=torch.float32, device=g.device)
+    _lib.run_roles([_lib.make_role(_lib.ROLE_SUM_ROWS, (part, gw), (nblk, C * F, 0))])
+    return gw.view(C, F)
+
+
+class GatThinFn(torch.autograd.Function):
+    """``GATConv`` on raw node features ``x [N, F <= 8]`` with the projection inside the attention kernels
+    (``qot_gat_fwd_thin`` / ``qot_gat_bwd_dst_thin``): ``z = x W^T`` is never written or read -- the kernels form a row where
+    the dense ones read it (F scalars of ``x`` and 4 F FMAs per float4, ``W^T`` in LDS).  The logits are
+    ``a[n, h] = x_n . (W_h^T att_h)`` (two products of width 4), the attention vectors' gradient
+    ``sum_n ga[n, h] z[n, h, :] = W_h (ga[:, h]^T x)``; the weight gradient stays ``grad_z^T x`` with ``grad_z`` from the source
+    pass (which carries the logits' share).  Same mathematics as ``SkinnyLinearFn`` + ``GatFn``, other rounding of ``z``
+    (its sum runs over the F features in another order).  ``x`` gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, lin_weight, att_src, att_dst, bias, graph: GraphIndex, neg_slope: float, bn_stats: bool = False):
+        require_cuda(x, lin_weight, att_src, att_dst, bias)
+        x, w, bias = _f32c(x), _f32c(lin_weight), _f32c(bias)
+        heads, C = att_src.shape[-2], att_src.shape[-1]
+        N, F = x.shape
+        HC = heads * C
+        dev = x.device
+        w3 = w.view(heads, C, F)
+        v_src = (w3 * _f32c(att_src).view(heads, C, 1)).sum(1).contiguous()          # [heads, F]
+        v_dst = (w3 * _f32c(att_dst).view(heads, C, 1)).sum(1).contiguous()
+        a_src = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        _lib.call("qot_skinny_linear_fwd", P(x), P(v_src), P(a_src), N, F, heads)
+        _lib.call("qot_skinny_linear_fwd", P(x), P(v_dst), P(a_dst), N, F, heads)
+        out = torch.empty(N, HC, dtype=torch.float32, device=dev)
+        stats = torch.empty(N, heads, 2, dtype=torch.float32, device=dev)
+        partials = None
+        if bn_stats and N > 0:
+            partials = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
+        _lib.call("qot_gat_fwd_thin", P(x), F, P(w), P(a_src), P(a_dst), P(bias), P(graph.rowptr), P(graph.col), P(out),
+                  P(stats), N, heads, C, float(neg_slope), P(partials))
+        ctx.save_for_backward(x, w, a_src, a_dst, stats, _f32c(att_src).reshape(-1), _f32c(att_dst).reshape(-1))
+        ctx.graph, ctx.ns, ctx.att_shape = graph, float(neg_slope), tuple(att_src.shape)
+        if bn_stats:
+            if partials is None:
+                partials = torch.empty(0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(partials)
+            return out, partials
+        return out
+
+    @staticmethod
+    def backward(ctx, g, _gp=None):
+        x, w, a_src, a_dst, stats, att_s, att_d = ctx.saved_tensors
+        graph, ns = ctx.graph, ctx.ns
+        g = _f32c(g)
+        N, F = x.shape
+        heads = a_src.shape[1]
+        HC = w.shape[0]
+        C = HC // heads
+        dev = x.device
+        gad = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        gas = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        gz = torch.empty(N, HC, dtype=torch.float32, device=dev)
+        escr = torch.empty(max(graph.cap, 1), heads, 2, dtype=torch.float32, device=dev)
+        delta = torch.empty(N, heads, dtype=torch.float32, device=dev)
+        g_bias = torch.empty(HC, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.load().qot_gat_bn_partials_floats(N, heads, C), dtype=torch.float32, device=dev)
+        _lib.call("qot_gat_bwd_dst_thin", P(g), P(x), F, P(w), P(a_src), P(a_dst), P(stats), P(graph.rowptr), P(graph.col),
+                  P(gad), P(escr), P(delta), N, heads, C, ns, P(g_bias), P(ws))
+        _lib.call("qot_gat_bwd_src", P(g), P(a_src), P(a_dst), P(escr), P(delta), P(graph.rowptr_t),
+                  P(graph.col_t), P(graph.pos_t), P(gz), P(gas), N, heads, C, ns, P(att_s), P(att_d), P(gad))
+        g_lin = _skinny_dw(gz, x)                                                    # [HC, F]
+        w3 = w.view(heads, C, F)
+        g_att_src = (w3 * _skinny_dw(gas, x).view(heads, 1, F)).sum(-1)              # [heads, C]
+        g_att_dst = (w3 * _skinny_dw(gad, x).view(heads, 1, F)).sum(-1)
+        return (None, g_lin, g_att_src.view(ctx.att_shape), g_att_dst.view(ctx.att_shape), g_bias, None, None, None)
+
+
 # ------------------------------------------------------------------ BatchNorm (+ReLU) (a8)
 def _dist_world():
     import torch.distributed as dist

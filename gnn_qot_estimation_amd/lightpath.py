@@ -105,7 +105,10 @@ class LightpathGNN(nn.Module):
         for layer in range(1, self.num_layers + 1):
             conv, norm = getattr(self, f"conv{layer}"), getattr(self, f"norm{layer}")
             # (the projection's epilogue also leaves the layer's attention logits where a head is 128 channels wide)
-            if pending is None:
+            thin = pending is None and conv.thin_ok(x)      # raw features: the projection inside the attention kernels
+            if thin:
+                z, logits = None, None
+            elif pending is None:
                 z, logits = conv.project(x, with_logits=True)
             else:                  # relu(norm(x)) @ W^T with the normalised activations never written to memory
                 pnorm, praw, ppart = pending
@@ -115,10 +118,11 @@ class LightpathGNN(nn.Module):
                     z, logits = pnorm.project_relu(praw, conv.lin.weight, partials=ppart), None
                 pending = None
             if self.training:      # the conv's epilogue leaves the BatchNorm's column partials behind
-                raw, part = conv.attend(z, graph, bn_stats=True, logits=logits)
+                raw, part = (conv.attend_thin(x, graph, bn_stats=True) if thin else
+                             conv.attend(z, graph, bn_stats=True, logits=logits))
                 partials = (part, conv.bias)
             else:
-                raw, partials = conv.attend(z, graph, logits=logits), None
+                raw, partials = (conv.attend_thin(x, graph) if thin else conv.attend(z, graph, logits=logits)), None
             width = raw.shape[1]
             # BatchNorm + ReLU folded into the NEXT projection's operand load (QF.BnLinearFn): the normalised activations are
             # never written to / read from HBM (one [N, 4C] tensor less resident per layer); the product runs on

@@ -175,6 +175,8 @@ class GATConv(nn.Module):
             graph = build_graph_index(edge_index, n, gat_self_loops=True)
         if not graph.gat_self_loops:
             raise ValueError("GATConv needs a GraphIndex built with gat_self_loops=True")
+        if self.thin_ok(x):
+            return self.attend_thin(x, graph, bn_stats)
         return self.attend(self.project(x), graph, bn_stats)
 
     def project(self, x, with_logits: bool = False):
@@ -197,6 +199,14 @@ class GATConv(nn.Module):
         else:
             z = self.lin(x)
         return (z, logits) if with_logits else z
+
+    def thin_ok(self, x) -> bool:
+        """The first layer's form: projection inside the attention kernels (``QF.GatThinFn``)."""
+        return self.heads == 4 and QF.gat_thin_ok(x, self.heads, self.out_channels)
+
+    def attend_thin(self, x, graph: GraphIndex, bn_stats: bool = False):
+        return QF.GatThinFn.apply(x, self.lin.weight, self.att_src, self.att_dst, self.bias, graph, self.negative_slope,
+                                  bn_stats)
 
     def attend(self, z, graph: GraphIndex, bn_stats: bool = False, logits=None):
         # attention logits a[n,h] = <z[n,h,:], att[h,:]> are formed from z inside the operator (one pass over z each

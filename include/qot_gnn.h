@@ -378,6 +378,19 @@ int qot_gat_logits(const float* z, const float* att_src, const float* att_dst, f
 int qot_gat_fwd(const float* z, const float* a_src, const float* a_dst, const float* bias,
                 const int32_t* rowptr, const int32_t* col, float* out, float* stats, int64_t N,
                 int heads, int C, float neg_slope, float* bn_partials, qot_stream_t stream);
+/* Thin forms (r04): the layer's projection z = x W^T (x [N, K], K <= 8 input features -- LightpathGNN's first layer, K = 5;
+ * W [heads*C, K] = GATConv.lin.weight) is formed inside the attention kernels, so that z is never written or read.  Same
+ * outputs and partials layout as qot_gat_fwd / qot_gat_bwd_dst; a_src / a_dst are the caller's (x (W_h^T att_h): two
+ * qot_skinny_linear_fwd of width 4).  qot_gat_thin_supported: 1 when K is in 1..8 and W^T fits next to the walk's LDS image;
+ * the entry points return QOT_ERR_UNSUPPORTED otherwise. */
+int qot_gat_thin_supported(int heads, int C, int K);
+int qot_gat_fwd_thin(const float* x, int K, const float* w, const float* a_src, const float* a_dst, const float* bias,
+                     const int32_t* rowptr, const int32_t* col, float* out, float* stats, int64_t N, int heads, int C,
+                     float neg_slope, float* bn_partials, qot_stream_t stream);
+int qot_gat_bwd_dst_thin(const float* grad_out, const float* x, int K, const float* w, const float* a_src,
+                         const float* a_dst, const float* stats, const int32_t* rowptr, const int32_t* col,
+                         float* grad_a_dst, float* escr, float* delta, int64_t N, int heads, int C, float neg_slope,
+                         float* grad_bias, float* workspace, qot_stream_t stream);
 /* destination pass: grad_a_dst[N,heads], escr[cap, heads, 2] = (alpha, dalpha), delta[N,heads].
  * grad_bias != NULL: also GATConv's bias gradient [heads*C] = column sums of grad_out (every row passes through this
  * kernel once anyway); workspace: qot_gat_bn_partials_floats(N, heads, C) floats. */

@@ -44,10 +44,20 @@ _LARGE = [("chain", 70001, 4), ("band", 70001, 16), ("hubs", 70001, 4), ("chain"
           ("hubs", 9001, 128), ("shuffled_chain", 9001, 128), ("band", 9001, 128), ("band", 9001, 256), ("chain", 13001, 256)]
 
 
+@pytest.mark.parametrize("thin", [False, True])
 @pytest.mark.parametrize("kind,n,C", _SMALL + _LARGE)
-def test_gatconv_walk_matches_oracle(cuda_device, kind, n, C):
+def test_gatconv_walk_matches_oracle(cuda_device, monkeypatch, kind, n, C, thin):
+    """``thin``: the first layer's form (``GatThinFn``: the projection of the 5 input features formed inside the attention
+    kernels, z never materialised) at every size; otherwise the dense kernels behind the skinny projection."""
     import gnn_qot_estimation_amd as q
+    from gnn_qot_estimation_amd import _lib
     from oracle import sparse as O
+    if thin:
+        if not _lib.load().qot_gat_thin_supported(4, C, 5):
+            pytest.skip("W^T does not fit next to the walk's LDS image at this width")
+        monkeypatch.setenv("QOT_GAT_THIN_MIN_ROWS", "1")
+    else:
+        monkeypatch.setenv("QOT_NO_GAT_THIN", "1")
     torch.manual_seed(1)
     ref = O.GATConv(5, C, heads=4)
     hip = q.GATConv(5, C, heads=4)
@@ -64,6 +74,7 @@ def test_gatconv_walk_matches_oracle(cuda_device, kind, n, C):
     xh = x.clone().to(cuda_device).requires_grad_(True)
     out = hip(xh, ei.to(cuda_device))
     (out * w.to(cuda_device)).sum().backward()
+    assert hip.thin_ok(x.to(cuda_device)) == thin
     assert rel_err(out, out_ref) <= TOL, (kind, C)
     assert rel_err(xh.grad, xr.grad) <= TOL, (kind, C)
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
