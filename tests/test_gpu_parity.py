@@ -134,9 +134,13 @@ def test_non_finite_node_feature_stays_in_its_graph(cuda_device, H):
     assert bool(torch.isnan(out[0]).any()) and bool(torch.isfinite(out[1:]).all())
 
 
+@pytest.mark.parametrize("thin", [False, True])
 @pytest.mark.parametrize("B,C,train", [(64, 32, True), (64, 32, False), (17, 128, True), (5, 8, True)])
-def test_lightpath_fwd_bwd(cuda_device, B, C, train):
+def test_lightpath_fwd_bwd(cuda_device, monkeypatch, B, C, train, thin):
+    """``thin``: the first GATConv in the form large batches take (``GatThinFn``: projection inside the attention kernels,
+    BatchNorm statistics from ITS epilogue's partials), forced at this size."""
     from gnn_qot_estimation_amd import synthetic as S
+    monkeypatch.setenv("QOT_GAT_THIN_MIN_ROWS", "1" if thin else "1000000000")
     batch = S.lightpath_batch(B)
     ref, hip = _models("lp", cuda_device, in_channels=5, hidden_channels=C, output_dim=3, is_lut_index=1, dropout_p=0.0)
     ref.train(train); hip.train(train)
