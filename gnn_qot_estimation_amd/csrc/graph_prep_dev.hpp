@@ -69,6 +69,41 @@ __device__ __forceinline__ void block_scan_into(const int* __restrict__ cnt, int
     __syncthreads();
 }
 
+// The in- and out-degree scans of one graph as ONE scan of packed pairs (in | out << 16; a graph's edge count is far below
+// 65536: its LDS image would not fit otherwise): exclusive scans of cin / cout [0..n) into rp / rpt [0..n], [n] = totals.
+// Half the barriers of two block_scan_into calls; for n <= NT (every reference-scale graph) no carry round trip either.
+template <int NT>
+__device__ __forceinline__ void block_scan_pair_into(const int* __restrict__ cin, const int* __restrict__ cout,
+                                                     int* __restrict__ rp, int* __restrict__ rpt, int n) {
+    __shared__ int carry_p;
+    if (n <= NT) {
+        const int idx = threadIdx.x;
+        const int v = idx < n ? (cin[idx] | (cout[idx] << 16)) : 0;
+        int total;
+        const int ex = block_exclusive_scan<NT>(v, &total);
+        if (idx < n) { rp[idx] = ex & 0xFFFF; rpt[idx] = (int)((unsigned)ex >> 16); }
+        if (idx == 0) { rp[n] = total & 0xFFFF; rpt[n] = (int)((unsigned)total >> 16); }
+        __syncthreads();
+        return;
+    }
+    if (threadIdx.x == 0) carry_p = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += NT) {
+        const int idx = c0 + threadIdx.x;
+        const int v = idx < n ? (cin[idx] | (cout[idx] << 16)) : 0;
+        int total;
+        const int ex = block_exclusive_scan<NT>(v, &total);
+        const int carry = carry_p;
+        const int s2 = carry + ex;                       // (both halves stay below 65536: no carry between them)
+        if (idx < n) { rp[idx] = s2 & 0xFFFF; rpt[idx] = (int)((unsigned)s2 >> 16); }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_p = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { rp[n] = carry_p & 0xFFFF; rpt[n] = (int)((unsigned)carry_p >> 16); }
+    __syncthreads();
+}
+
 // NT threads per workgroup: 256 inside the multi-role launch; 1024 in a launch of its own for graphs whose LDS image
 // leaves one workgroup per CU anyway (csr_by_graph_wide_kernel: every phase is a loop over the graph's edges or rows)
 template <int NT = 256>
@@ -146,8 +181,12 @@ __device__ __forceinline__ void csr_by_graph_body(
     }
     if (bad && status) atomicOr(status, 1);
     __syncthreads();
-    block_scan_into<NT>(cin, rp, n);
-    block_scan_into<NT>(cout, rpt, n);
+    if (m < 65536) {
+        block_scan_pair_into<NT>(cin, cout, rp, rpt, n);
+    } else {
+        block_scan_into<NT>(cin, rp, n);
+        block_scan_into<NT>(cout, rpt, n);
+    }
     for (int e = threadIdx.x; e < m; e += NT) {
         const unsigned int ji = ends[e];
         key_in[rp[ji & 0xFFFFu] + rank_in[e]] = e;
